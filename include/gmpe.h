@@ -1,0 +1,215 @@
+/* gmpe.h — C ABI of the MI355X batched GraphMPE step engine (libgmpe.so).
+ *
+ * This is the drop-in boundary for ONE hot path of Jaroan/Contracts-MARL-AAM-Corridors: the
+ * per-environment particle-world step + graph observation, batched over N environments.
+ * It replaces what `GraphSubprocVecEnv` (onpolicy/envs/env_wrappers.py:959-1037) obtains from its
+ * N worker processes, each of which runs `MultiAgentGraphEnv.step/reset`
+ * (multiagent/environment.py:1021-1081) on `World.step` (multiagent/core.py:687-756) with the
+ * scenario callbacks of multiagent/custom_scenarios/nav_metered_one_goal_graph_rotate_tube_july.py.
+ *
+ * Conventions
+ *  - plain C: POD structs, raw pointers, sizes. No torch / C++ types cross this boundary.
+ *  - every function returns 0 on success or a negative gmpe_status; gmpe_last_error() gives text.
+ *    No exception crosses the ABI.
+ *  - "dev" pointers are device (HBM) pointers owned by the CALLER (e.g. torch tensors'
+ *    data_ptr()); "host" pointers are ordinary host memory. The handle owns only the persistent
+ *    SoA world state and a few KB of scratch; step/reset never allocate.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream). step/reset are
+ *    asynchronous on it; get/set_field synchronise the handle's stream themselves.
+ *  - one handle per GPU; handles are not thread-safe.
+ *
+ * Shapes: N envs, A agents, L landmarks, O obstacles, E = A+L+O graph nodes, F = 8 node features,
+ * D = observation width (19 tube_july, 13 navigation_graph).
+ */
+#ifndef GMPE_H
+#define GMPE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMPE_ABI_VERSION 1
+#define GMPE_NODE_FEATS 8          /* …_july.py:1771  [rel_vel2, rel_pos2, rel_goal2, occupied, type] */
+#define GMPE_INFO_KEYS 17          /* …_july.py:806-828 + 'individual_reward' (environment.py:1048)  */
+#define GMPE_MAX_AGENTS 64         /* one wavefront lane per agent in the sequential-semantics pass   */
+#define GMPE_MAX_ENTITIES 160
+#define GMPE_MAX_WALLS 8
+#define GMPE_TUBE_STRIDE 12
+
+typedef enum gmpe_status {
+    GMPE_OK = 0,
+    GMPE_ERR_INVALID_ARG = -1,
+    GMPE_ERR_HIP = -2,              /* a HIP runtime call failed (text in gmpe_last_error)            */
+    GMPE_ERR_NO_DEVICE = -3,
+    GMPE_ERR_UNSUPPORTED = -4,
+    GMPE_ERR_TAPE_EXHAUSTED = -5,   /* parity mode: an env needed more uniform draws than the tape has */
+    GMPE_ERR_PLACEMENT = -6         /* reset: rejection sampler hit GMPE_MAX_PLACEMENT_TRIES           */
+} gmpe_status;
+
+/* Scenarios (multiagent/custom_scenarios/<name>.py). */
+typedef enum gmpe_scenario {
+    GMPE_SCENARIO_NAVIGATION_GRAPH = 0, /* not shipped by the reference (train_mpe.py:72-73 default only):
+                                           restated from extant blocks, see DESIGN.md §navigation_graph */
+    GMPE_SCENARIO_TUBE_JULY = 1         /* nav_metered_one_goal_graph_rotate_tube_july.py               */
+} gmpe_scenario;
+
+/* Dynamics (multiagent/core.py:23-26 EntityDynamicsType). */
+typedef enum gmpe_dynamics {
+    GMPE_DYN_DOUBLE_INTEGRATOR = 0,     /* force path: core.py:766-845, 872-964                       */
+    GMPE_DYN_UNICYCLE = 1,              /* kinematic, UnicycleVehicleConfig constants                 */
+    GMPE_DYN_AIR_TAXI = 2               /* kinematic: core.py:231-340, 819-826                        */
+} gmpe_dynamics;
+
+typedef struct gmpe_wall {              /* multiagent/core.py:354-373 Wall                             */
+    int32_t orient;                     /* 0 = 'H' (lies along x at y = axis_pos), 1 = 'V'            */
+    int32_t hard;
+    double axis_pos;
+    double end0, end1;
+    double width;
+} gmpe_wall;
+
+/* Everything the reference reads from `args` (…_july.py:155-192,206-224,248-259,274,315,326) and
+ * from multiagent/config.py, frozen into one POD. The Python host fills it (gmpe/config.py). */
+typedef struct gmpe_config {
+    int32_t abi_version;                /* GMPE_ABI_VERSION                                            */
+    int32_t scenario;                   /* gmpe_scenario                                               */
+    int32_t dynamics;                   /* gmpe_dynamics                                               */
+    int32_t num_envs;                   /* N on this handle                                            */
+    int32_t num_agents;                 /* A  (== num_landmarks: goal i belongs to agent i, :356)      */
+    int32_t num_landmarks;              /* L                                                           */
+    int32_t num_obstacles;              /* O                                                           */
+    int32_t num_walls;                  /* physics only, never graph nodes                             */
+    int32_t episode_length;             /* world.world_length (environment.py:264-271)                 */
+    int32_t env_id_base;                /* global id of env 0 of this handle: RNG key = seed, id       */
+    int32_t n_actions;                  /* 25 (5x5 motion primitives) or 5 / 9 (double integrator)     */
+    int32_t collaborative;              /* shared reward (environment.py:1056-1061)                    */
+    uint64_t seed;
+    double world_size;
+    double max_speed;                   /* args.max_speed (agent.max_speed; <=0 means None)            */
+    double collision_rew, formation_rew, goal_rew;
+    double min_reward, max_reward;      /* RewardWeightConfig.MIN/MAX_REWARD (config.py:135-136)       */
+    /* multiagent/config.py constants of the chosen dynamics */
+    double dt;
+    double v_min, v_max;                /* kinematic speed clamp (core.py:309-312); DI: v_max = VX_MAX */
+    double goal_thresh;                 /* DISTANCE_TO_GOAL_THRESHOLD                                  */
+    double sep_dist;                    /* COLLISION_DISTANCE (= SEPARATION_DISTANCE for air_taxi)     */
+    double coord_range;                 /* COORDINATION_RANGE: update_graph max_edge_dist (:242)       */
+    double ang_rate_opt[5];             /* np.linspace(-ANGULAR_RATE_MAX, +, 5) (environment.py:441)   */
+    double accel_opt[5];                /* np.linspace(ACCEL_MIN, ACCEL_MAX, 5)   (environment.py:440) */
+    double sensitivity;                 /* 5.0 (environment.py:460-463)                                */
+    double entity_size;                 /* Entity.size = 0.06 (core.py:385)                            */
+    /* force path (core.py:542-548) */
+    double damping, contact_force, contact_margin, wall_contact_force, wall_contact_margin;
+    gmpe_wall walls[GMPE_MAX_WALLS];
+} gmpe_config;
+
+/* Persistent per-env state, addressable for checkpoint / parity injection. */
+typedef enum gmpe_field {
+    GMPE_F_X = 0,            /* f64 [N,A]                                                               */
+    GMPE_F_Y,                /* f64 [N,A]                                                               */
+    GMPE_F_S2,               /* f64 [N,A]  air_taxi/unicycle: theta        double_integrator: v_x       */
+    GMPE_F_S3,               /* f64 [N,A]  air_taxi/unicycle: speed        double_integrator: v_y       */
+    GMPE_F_P_DIST,           /* f64 [N,A]  odometer (core.py:315)                                       */
+    GMPE_F_TIME,             /* f64 [N,A]  (core.py:316)                                                */
+    GMPE_F_STATUS,           /* u8  [N,A]  agent.status (done)                                          */
+    GMPE_F_PREV_PHASE,       /* i32 [N,A]  agent.previous_phase — survives resets (…_july.py:708-710)   */
+    GMPE_F_PHASE_REACHED,    /* i32 [N,A]                                                               */
+    GMPE_F_COOLDOWN,         /* i32 [N,A]  entry_reward_cooldown (never armed in the July file)         */
+    GMPE_F_GOAL_TRACKER,     /* i32 [N,A]                                                               */
+    GMPE_F_CURRENT_STEP,     /* i32 [N]                                                                 */
+    GMPE_F_RNG_CTR,          /* i64 [N]    uniform draws consumed so far by this env                    */
+    GMPE_F_TUBE,             /* f64 [N,12] angle, ent.xy, exit.xy, e.xy, n.xy(fp32-rounded), L, half_w, width */
+    GMPE_F_LANDMARKS,        /* f64 [N,L,2]                                                             */
+    GMPE_F_OBSTACLES,        /* f64 [N,O,2]                                                             */
+    /* info counters (…_july.py:741-829); the int-typed ones reproduce the reference's np.full(n,-1)
+       int64 arrays, into which floats are truncated on assignment */
+    GMPE_F_TIMES_REQUIRED,   /* i32 [N,A] */
+    GMPE_F_DISTS_TO_GOAL,    /* i32 [N,A] */
+    GMPE_F_DIST_LEFT,        /* i32 [N,A] */
+    GMPE_F_GOAL_REACHED,     /* i32 [N,A] */
+    GMPE_F_N_AGENT_COLL,     /* i32 [N,A] */
+    GMPE_F_N_OBST_COLL,      /* i32 [N,A] */
+    GMPE_F_SPACING_VIOL,     /* i32 [N,A] */
+    GMPE_F_STEPS_IN_CORR,    /* i32 [N,A] */
+    GMPE_F_CONFORMANCE,      /* i32 [N,A] */
+    GMPE_F_GOAL_MIN_TIME,    /* f64 [N,A] agent.goal_min_time (…_july.py:941-951)                       */
+    GMPE_F_DELTA_SPACING,    /* f64 [N]   running sum of the delta_spacing list (:1180, :802)           */
+    GMPE_F_ERROR_FLAGS,      /* i32 [N]   sticky: bit0 tape exhausted, bit1 placement gave up           */
+    GMPE_F_COUNT
+} gmpe_field;
+
+typedef struct gmpe_handle gmpe_handle;
+
+/* Output buffers of one step/reset, all caller-owned DEVICE memory. Any pointer may be NULL to
+ * skip that output. Layout = what GraphSubprocVecEnv.step_wait stacks (env_wrappers.py:996-1004),
+ * narrowed to the dtypes GraphReplayBuffer stores (onpolicy/utils/graph_buffer.py:84-114). */
+typedef struct gmpe_outputs {
+    float*   obs;        /* [N,A,D]                                                                    */
+    int32_t* agent_id;   /* [N,A,1]                    (…_july.py:1554-1555)                           */
+    float*   node_obs;   /* [N,A,E,F]                  (…_july.py:1584-1624, 1694-1771)                */
+    float*   adj;        /* adj_compact ? [N,E,E] : [N,A,E,E]  (…_july.py:1625-1648)                   */
+    float*   reward;     /* [N,A]   (step only)        (…_july.py:1105-1221)                           */
+    uint8_t* done;       /* [N,A]   (step only)        (environment.py:264-271)                        */
+    float*   info;       /* [N,A,GMPE_INFO_KEYS] (step only; optional) (…_july.py:741-829)             */
+    int32_t  adj_compact;/* 1: write the single E×E matrix every ego shares            */
+    int32_t  reserved;
+} gmpe_outputs;
+
+int gmpe_abi_version(void);
+const char* gmpe_last_error(void);
+
+/* Observation width D and node count E for a config (no device needed). */
+int gmpe_obs_dim(const gmpe_config* cfg);
+int gmpe_num_entities(const gmpe_config* cfg);
+
+/* Create the engine on HIP device `device`. Replaces N x `GraphMPEEnv(args)` + `env.seed(seed +
+ * rank*1000)` (multiagent/MPE_env.py:56-84, onpolicy/scripts/train_mpe.py:21-43). */
+int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out);
+int gmpe_destroy(gmpe_handle* h);
+
+/* Parity mode: replay the reference's np.random draws. `tape_dev` is DEVICE memory, f64
+ * [N, len_per_env] of [0,1) samples; draw k of env n is tape[n*len+k]. NULL returns to the
+ * counter-based Philox4x32-10 stream keyed by (seed, env_id_base+n, k). */
+int gmpe_set_rng_tape(gmpe_handle* h, const double* tape_dev, int64_t len_per_env);
+
+/* Replaces GraphSubprocVecEnv.reset (env_wrappers.py:1006-1013 → environment.py:1066-1081 →
+ * …_july.py:339-420). `env_mask_dev` (u8 [N], device) selects envs; NULL = all. */
+int gmpe_reset(gmpe_handle* h, const uint8_t* env_mask_dev, const gmpe_outputs* out, void* stream);
+
+/* Replaces GraphSubprocVecEnv.step (env_wrappers.py:991-1004 → graphworker :851-873 →
+ * environment.py:1021-1063), including the worker's auto-reset: envs whose agents are all done
+ * return their POST-reset obs/agent_id/node_obs/adj with the terminal reward/done.
+ * `action_idx_dev`: i32 [N,A] discrete action index (argmax of the runner's one-hot,
+ * environment.py:446). */
+int gmpe_step(gmpe_handle* h, const int32_t* action_idx_dev, const gmpe_outputs* out, void* stream);
+
+/* Same, taking the runner's float one-hot [N,A,n_actions] (graph_mpe_runner.py:375-377); the
+ * argmax (np.argmax: first maximum) is fused into the step kernel. */
+int gmpe_step_onehot(gmpe_handle* h, const float* onehot_dev, const gmpe_outputs* out, void* stream);
+
+/* Host <-> engine state copies (whole field, `bytes` must equal the field's size). */
+int gmpe_field_bytes(const gmpe_handle* h, int field, size_t* bytes);
+int gmpe_get_field(gmpe_handle* h, int field, void* host_dst, size_t bytes);
+int gmpe_set_field(gmpe_handle* h, int field, const void* host_src, size_t bytes);
+
+/* Learner-side edge set of onpolicy/algorithms/utils/gnn_new.py:329-358 (process_adj):
+ * mask = (adj < max_edge_dist) & (adj > 0) on fp32, edges in (batch,row,col) lexicographic order,
+ * node ids offset by batch*E. adj_dev: f32 [B,E,E]. Outputs: edge_index i32 [2,cap] (row 0 = src,
+ * row 1 = dst), edge_attr f32 [cap], n_edges i32 [1] (device). If more than `cap` edges exist only
+ * the first `cap` are written and n_edges still holds the true count. */
+int gmpe_edges_from_adj(gmpe_handle* h, const float* adj_dev, int32_t batch, int32_t num_nodes,
+                        float max_edge_dist, int32_t inclusive, int32_t* edge_index_dev,
+                        float* edge_attr_dev, int32_t cap, int32_t* n_edges_dev, void* stream);
+
+/* Timing hooks used by bench.py: HIP events on the handle's launch stream around every step
+ * kernel, so the dominant kernel's duration is measured live (not via torch's current stream). */
+int gmpe_timing_enable(gmpe_handle* h, int32_t enable);
+int gmpe_timing_read(gmpe_handle* h, double* total_ms, int64_t* launches, int32_t reset_counters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMPE_H */
