@@ -1,0 +1,62 @@
+"""ctypes binding of libgmpe.so (include/gmpe.h). No CPU fallback: a missing library raises."""
+import ctypes as C
+import os
+
+from .config import GmpeConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgmpe.so")
+_lib = None
+
+SYMBOLS = ["gmpe_abi_version", "gmpe_last_error", "gmpe_obs_dim", "gmpe_num_entities", "gmpe_create",
+           "gmpe_destroy", "gmpe_set_rng_tape", "gmpe_reset", "gmpe_step", "gmpe_step_onehot",
+           "gmpe_field_bytes", "gmpe_get_field", "gmpe_set_field", "gmpe_edges_from_adj",
+           "gmpe_timing_enable", "gmpe_timing_read"]
+
+
+class GmpeOutputs(C.Structure):
+    _fields_ = [("obs", C.c_void_p), ("agent_id", C.c_void_p), ("node_obs", C.c_void_p),
+                ("adj", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),
+                ("info", C.c_void_p), ("adj_compact", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GmpeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgmpe.so. torch must be imported first so that the engine binds to the SAME HIP
+    runtime (libamdhip64.so.7) torch uses; two runtimes in one process cannot share device memory."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GmpeError("libgmpe.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "or `make -C contracts-marl-aam-corridors_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    import torch  # noqa: F401  (loads libamdhip64 first)
+    lib = C.CDLL(LIB_PATH)
+    P, I = C.c_void_p, C.c_int
+    lib.gmpe_last_error.restype = C.c_char_p
+    lib.gmpe_obs_dim.argtypes = [C.POINTER(GmpeConfig)]
+    lib.gmpe_num_entities.argtypes = [C.POINTER(GmpeConfig)]
+    lib.gmpe_create.argtypes = [C.POINTER(GmpeConfig), I, C.POINTER(P)]
+    lib.gmpe_destroy.argtypes = [P]
+    lib.gmpe_set_rng_tape.argtypes = [P, P, C.c_int64]
+    lib.gmpe_reset.argtypes = [P, P, C.POINTER(GmpeOutputs), P]
+    lib.gmpe_step.argtypes = [P, P, C.POINTER(GmpeOutputs), P]
+    lib.gmpe_step_onehot.argtypes = [P, P, C.POINTER(GmpeOutputs), P]
+    lib.gmpe_field_bytes.argtypes = [P, I, C.POINTER(C.c_size_t)]
+    lib.gmpe_get_field.argtypes = [P, I, P, C.c_size_t]
+    lib.gmpe_set_field.argtypes = [P, I, P, C.c_size_t]
+    lib.gmpe_edges_from_adj.argtypes = [P, P, C.c_int32, C.c_int32, C.c_float, C.c_int32, P, P, C.c_int32, P, P]
+    lib.gmpe_timing_enable.argtypes = [P, C.c_int32]
+    lib.gmpe_timing_read.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]
+    if lib.gmpe_abi_version() != 1:
+        raise GmpeError("libgmpe.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise GmpeError("%s failed (%d): %s" % (what, rc, load().gmpe_last_error().decode()))

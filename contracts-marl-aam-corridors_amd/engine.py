@@ -1,0 +1,164 @@
+"""GmpeEngine — thin Python owner of one gmpe_handle (one per GPU) + the torch output buffers.
+
+PyTorch is plumbing only: device memory (`torch.empty(..., device=...)`), streams and
+`torch.distributed`. All arithmetic happens in the HIP kernels behind include/gmpe.h.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import FIELDS, INFO_KEYS, NODE_FEATS, GmpeConfig, algorithmic_bytes_per_env_step
+
+
+class StepOutputs(object):
+    """Device-resident outputs of one step/reset (torch tensors on the engine's device)."""
+    __slots__ = ("obs", "agent_id", "node_obs", "adj", "reward", "done", "info")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+
+class GmpeEngine(object):
+    def __init__(self, cfg, device=0, adj_compact=False, with_info=True):
+        if not isinstance(cfg, GmpeConfig):
+            raise TypeError("cfg must be a gmpe.config.GmpeConfig")
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.GmpeError("no MI355X visible to torch: the engine has no CPU fallback")
+        self.cfg = cfg
+        self.device = torch.device("cuda", int(device))
+        self.N, self.A = cfg.num_envs, cfg.num_agents
+        self.E, self.D = cfg.num_entities, cfg.obs_dim
+        self.adj_compact = bool(adj_compact)
+        self.h = C.c_void_p()
+        _lib.check(self.lib.gmpe_create(C.byref(cfg), self.device.index, C.byref(self.h)), "gmpe_create")
+        N, A, E, D = self.N, self.A, self.E, self.D
+        dev = self.device
+        self.out = StepOutputs(
+            obs=torch.empty((N, A, D), dtype=torch.float32, device=dev),
+            agent_id=torch.empty((N, A, 1), dtype=torch.int32, device=dev),
+            node_obs=torch.empty((N, A, E, NODE_FEATS), dtype=torch.float32, device=dev),
+            adj=torch.empty((N, E, E) if adj_compact else (N, A, E, E), dtype=torch.float32, device=dev),
+            reward=torch.empty((N, A), dtype=torch.float32, device=dev),
+            done=torch.empty((N, A), dtype=torch.uint8, device=dev),
+            info=torch.empty((N, A, len(INFO_KEYS)), dtype=torch.float32, device=dev) if with_info else None)
+        self._tape = None
+        self._o = self._pack(self.out)
+
+    # ------------------------------------------------------------------ plumbing
+    def _pack(self, o):
+        p = lambda t: None if t is None else t.data_ptr()
+        return _lib.GmpeOutputs(p(o.obs), p(o.agent_id), p(o.node_obs), p(o.adj), p(o.reward), p(o.done),
+                                p(o.info), int(self.adj_compact), 0)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gmpe_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ hot path
+    def reset(self, mask=None):
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, dtype=torch.uint8, device=self.device).contiguous()
+        _lib.check(self.lib.gmpe_reset(self.h, None if m is None else m.data_ptr(), C.byref(self._o),
+                                       self._stream()), "gmpe_reset")
+        return self.out
+
+    def step(self, action_idx):
+        """action_idx: int32 device tensor [N,A]."""
+        a = action_idx
+        if a.dtype != torch.int32 or not a.is_contiguous() or a.device != self.device:
+            a = a.to(device=self.device, dtype=torch.int32).contiguous()
+        if a.numel() != self.N * self.A:
+            raise ValueError("action_idx must have N*A = %d elements" % (self.N * self.A))
+        _lib.check(self.lib.gmpe_step(self.h, a.data_ptr(), C.byref(self._o), self._stream()), "gmpe_step")
+        return self.out
+
+    def step_onehot(self, onehot):
+        """onehot: float32 device tensor [N,A,n_actions] (argmax fused into the kernel)."""
+        a = onehot
+        if a.dtype != torch.float32 or not a.is_contiguous() or a.device != self.device:
+            a = a.to(device=self.device, dtype=torch.float32).contiguous()
+        if a.numel() != self.N * self.A * self.cfg.n_actions:
+            raise ValueError("onehot must be [N,A,%d]" % self.cfg.n_actions)
+        _lib.check(self.lib.gmpe_step_onehot(self.h, a.data_ptr(), C.byref(self._o), self._stream()),
+                   "gmpe_step_onehot")
+        return self.out
+
+    # ------------------------------------------------------------------ state access
+    def get(self, name):
+        fid, dt, shp = FIELDS[name]
+        a = np.empty(shp(self.cfg), dtype=dt)
+        _lib.check(self.lib.gmpe_get_field(self.h, fid, a.ctypes.data_as(C.c_void_p), a.nbytes), "gmpe_get_field")
+        return a
+
+    def set(self, name, value):
+        fid, dt, shp = FIELDS[name]
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=dt), shp(self.cfg)))
+        _lib.check(self.lib.gmpe_set_field(self.h, fid, a.ctypes.data_as(C.c_void_p), a.nbytes), "gmpe_set_field")
+
+    def get_state(self):
+        return {k: self.get(k) for k in FIELDS}
+
+    def set_state(self, state):
+        for k, v in state.items():
+            self.set(k, v)
+
+    def set_tape(self, tape):
+        """Parity mode: f64 [N, len] of [0,1) samples replayed instead of Philox (None to disable)."""
+        if tape is None:
+            self._tape = None
+            _lib.check(self.lib.gmpe_set_rng_tape(self.h, None, 0), "gmpe_set_rng_tape")
+            return
+        t = torch.as_tensor(np.asarray(tape, dtype=np.float64).reshape(self.N, -1), device=self.device).contiguous()
+        torch.cuda.synchronize(self.device)
+        self._tape = t
+        _lib.check(self.lib.gmpe_set_rng_tape(self.h, t.data_ptr(), t.shape[1]), "gmpe_set_rng_tape")
+
+    def check_errors(self):
+        e = self.get("error_flags")
+        if (e & 1).any():
+            raise _lib.GmpeError("RNG tape exhausted in %d env(s)" % int((e & 1).astype(bool).sum()))
+        if (e & 2).any():
+            raise _lib.GmpeError("reset placement gave up in %d env(s) (world too small for the agents)"
+                                 % int((e & 2).astype(bool).sum()))
+
+    # ------------------------------------------------------------------ edges (learner-side process_adj)
+    def edges_from_adj(self, adj, max_edge_dist, inclusive=False, cap=None):
+        adj = adj.reshape(-1, adj.shape[-2], adj.shape[-1]).contiguous()
+        B, E = adj.shape[0], adj.shape[-1]
+        cap = int(cap if cap is not None else B * E * E)
+        ei = torch.empty((2, cap), dtype=torch.int32, device=self.device)
+        ea = torch.empty((cap,), dtype=torch.float32, device=self.device)
+        ne = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.gmpe_edges_from_adj(self.h, adj.data_ptr(), B, E, float(max_edge_dist), int(inclusive),
+                                                ei.data_ptr(), ea.data_ptr(), cap, ne.data_ptr(), self._stream()),
+                   "gmpe_edges_from_adj")
+        m = int(ne.item())
+        return ei[:, :min(m, cap)], ea[:min(m, cap)], m
+
+    # ------------------------------------------------------------------ timing hooks
+    def timing(self, enable):
+        _lib.check(self.lib.gmpe_timing_enable(self.h, int(bool(enable))), "gmpe_timing_enable")
+
+    def timing_read(self, reset=True):
+        ms, n = C.c_double(), C.c_int64()
+        _lib.check(self.lib.gmpe_timing_read(self.h, C.byref(ms), C.byref(n), int(reset)), "gmpe_timing_read")
+        return ms.value, n.value
+
+    @property
+    def bytes_per_env_step(self):
+        return algorithmic_bytes_per_env_step(self.cfg)

@@ -1,0 +1,274 @@
+"""GPU parity: the HIP engine (through the C ABI) vs the CPU oracle and vs the golden vectors.
+
+Bars (BASELINE.json north_star): positions/velocities/observations within 1e-5 in fp32, graph edge
+indices and dones bit-exact.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import gmpe
+from gmpe.config import INFO_KEYS
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+JULY = sorted(glob.glob(os.path.join(GOLD, "july_A*_s*.npz")))
+TOL = 1e-5
+
+
+def _engine(cfg, **kw):
+    from gmpe.engine import GmpeEngine
+    return GmpeEngine(cfg, device=0, **kw)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def edges_numpy(adj32, d, inclusive=False):
+    """process_adj rule (gnn_new.py:329-358) on a [B,E,E] float32 array."""
+    m = ((adj32 <= d) if inclusive else (adj32 < d)) & (adj32 > 0)
+    b, r, c = np.nonzero(m)
+    E = adj32.shape[-1]
+    return np.stack([b * E + r, b * E + c]).astype(np.int32), adj32[b, r, c]
+
+
+def _july_cfg(d, **kw):
+    return gmpe.make_config(scenario_name="nav_metered_one_goal_graph_rotate_tube_july",
+                            num_envs=1, num_agents=int(d["A"]), world_size=float(d["world_size"]),
+                            episode_length=int(d["episode_length"]), max_speed=float(d["max_speed"]),
+                            collision_rew=float(d["collision_rew"]), formation_rew=float(d["formation_rew"]),
+                            goal_rew=float(d["goal_rew"]), **kw)
+
+
+@pytest.mark.parametrize("path", JULY, ids=[os.path.basename(p)[:-4] for p in JULY])
+def test_golden_replay_on_gpu(path):
+    """The reference's own rollouts (incl. its np.random draws via the tape) replayed on the GPU."""
+    d = np.load(path)
+    A, E, T = int(d["A"]), int(d["E"]), int(d["T"])
+    eng = _engine(_july_cfg(d))
+    eng.set("prev_phase", d["init_prev_phase"][None])
+    eng.set_tape(d["tape"][None])
+    o = eng.reset()
+    np.testing.assert_allclose(_np(o.obs)[0], d["reset0_obs"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(_np(o.node_obs)[0], d["reset0_node"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(_np(o.adj)[0], np.broadcast_to(d["reset0_adj"], (A, E, E)), rtol=0, atol=TOL)
+    np.testing.assert_array_equal(_np(o.agent_id)[0], d["reset0_id"])
+    guided = bool(d["guided"])
+    n_inj = 0
+
+    def inject():
+        nonlocal n_inj
+        inj = d["inject"][n_inj]; n_inj += 1
+        eng.set("x", inj[None, :, 0]); eng.set("y", inj[None, :, 1]); eng.set("s2", inj[None, :, 2]); eng.set("s3", inj[None, :, 3])
+
+    if guided:
+        inject()
+    import torch
+    for t in range(T):
+        o = eng.step(torch.as_tensor(d["act"][t][None].astype(np.int32)))
+        np.testing.assert_allclose(_np(o.reward)[0], d["rew"][t], rtol=0, atol=TOL, err_msg="rew t=%d" % t)
+        np.testing.assert_array_equal(_np(o.done)[0].astype(bool), d["done"][t], err_msg="done t=%d" % t)
+        np.testing.assert_allclose(_np(o.obs)[0], d["ret_obs"][t], rtol=0, atol=TOL, err_msg="obs t=%d" % t)
+        np.testing.assert_allclose(_np(o.node_obs)[0], d["ret_node"][t], rtol=0, atol=TOL, err_msg="node t=%d" % t)
+        adj = _np(o.adj)[0]
+        np.testing.assert_allclose(adj, np.broadcast_to(d["ret_adj"][t], (A, E, E)), rtol=0, atol=TOL, err_msg="adj t=%d" % t)
+        np.testing.assert_array_equal(adj == 0, np.broadcast_to(d["ret_adj"][t] == 0, (A, E, E)))
+        np.testing.assert_allclose(_np(o.info)[0], d["info"][t], rtol=2e-6, atol=2e-5, err_msg="info t=%d" % t)
+        if not d["did_reset"][t]:
+            np.testing.assert_allclose(eng.get("x")[0], d["st_x"][t], rtol=0, atol=2e-6)
+            np.testing.assert_array_equal(eng.get("status")[0].astype(bool), d["st_status"][t])
+            np.testing.assert_array_equal(eng.get("prev_phase")[0], d["st_prev_phase"][t])
+            np.testing.assert_array_equal(eng.get("phase_reached")[0], d["st_phase_reached"][t])
+        elif guided:
+            inject()
+        assert eng.get("rng_ctr")[0] == d["tape_pos"][t + 1], "draw count t=%d" % t
+    eng.check_errors()
+    eng.close()
+
+
+def _compare_step(eo, oo, E, A, label):
+    obs, ids, node, adj, rew, done, info, did = oo
+    np.testing.assert_allclose(_np(eo.obs), obs, rtol=0, atol=TOL, err_msg=label + " obs")
+    np.testing.assert_allclose(_np(eo.node_obs), node, rtol=0, atol=TOL, err_msg=label + " node")
+    eadj = _np(eo.adj)
+    np.testing.assert_allclose(eadj, np.broadcast_to(adj[:, None], eadj.shape), rtol=0, atol=TOL, err_msg=label + " adj")
+    np.testing.assert_allclose(_np(eo.reward), rew, rtol=0, atol=TOL, err_msg=label + " rew")
+    np.testing.assert_array_equal(_np(eo.done).astype(bool), done, err_msg=label + " done")
+    np.testing.assert_allclose(_np(eo.info), info, rtol=2e-6, atol=2e-5, err_msg=label + " info")
+    np.testing.assert_array_equal(_np(eo.agent_id), ids)
+    # edge indices bit-exact under both thresholding rules (learner's `<` and update_graph's `<=`)
+    o32 = adj.astype(np.float32)
+    for dist, incl in ((1.0, False), (4.82802, True)):
+        e_ref, _ = edges_numpy(o32, dist, incl)
+        e_gpu, _ = edges_numpy(eadj[:, 0], dist, incl)
+        np.testing.assert_array_equal(e_gpu, e_ref, err_msg=label + " edge indices")
+
+
+STATE_F = ["x", "y", "s2", "s3", "p_dist", "time"]
+STATE_I = ["status", "prev_phase", "phase_reached", "cooldown", "goal_tracker", "current_step", "rng_ctr",
+           "times_required", "dists_to_goal", "dist_left", "goal_reached", "n_agent_coll", "n_obst_coll",
+           "spacing_viol", "steps_in_corr", "conformance", "error_flags"]
+
+
+def _compare_state(eng, orc, label):
+    for f in STATE_F + ["tube", "landmarks", "obstacles", "goal_min_time", "delta_spacing"]:
+        np.testing.assert_allclose(eng.get(f), orc.get(f), rtol=0, atol=1e-9, err_msg=label + " " + f)
+    for f in STATE_I:
+        np.testing.assert_array_equal(eng.get(f), orc.get(f), err_msg=label + " " + f)
+
+
+def _rollout_vs_oracle(cfg, steps, seed, shrink_world=False):
+    import torch
+    eng = _engine(cfg)
+    orc = ol.Oracle(cfg)
+    rng = np.random.RandomState(seed)
+    eo = eng.reset(); oo = orc.reset()
+    np.testing.assert_allclose(_np(eo.obs), oo[0], rtol=0, atol=TOL)
+    np.testing.assert_allclose(_np(eo.node_obs), oo[2], rtol=0, atol=TOL)
+    _compare_state(eng, orc, "reset")
+    if shrink_world:
+        # pull the agents close to the tube so phases 1/2, goal reaches and collisions happen
+        st = {k: orc.get(k) for k in ("x", "y", "s2", "s3", "tube")}
+        N, A = cfg.num_envs, cfg.num_agents
+        e = st["tube"][:, 5:7]; ent = st["tube"][:, 1:3]
+        k = np.arange(A)[None, :, None]
+        pos = ent[:, None, :] - e[:, None, :] * (0.1 + 0.2 * k) + rng.uniform(-0.1, 0.1, (N, A, 2))
+        th = np.arctan2(e[:, 1], e[:, 0])[:, None] + rng.uniform(-0.2, 0.2, (N, A))
+        for tgt in (eng, orc):
+            tgt.set("x", pos[..., 0]); tgt.set("y", pos[..., 1]); tgt.set("s2", th); tgt.set("s3", np.full((N, A), 0.08))
+    n_resets = 0
+    for t in range(steps):
+        if shrink_world:
+            # steer roughly along the tube: keep heading (w index 2) mostly, full accel
+            act = np.where(rng.rand(cfg.num_envs, cfg.num_agents) < 0.7, 2 * 5 + 4, rng.randint(0, cfg.n_actions, (cfg.num_envs, cfg.num_agents)))
+        else:
+            act = rng.randint(0, cfg.n_actions, (cfg.num_envs, cfg.num_agents))
+        act = act.astype(np.int32)
+        eo = eng.step(torch.as_tensor(act))
+        oo = orc.step(act)
+        _compare_step(eo, oo, cfg.num_entities, cfg.num_agents, "t=%d" % t)
+        _compare_state(eng, orc, "t=%d" % t)
+        n_resets += int(oo[7].sum())
+    eng.check_errors()
+    eng.close()
+    return n_resets
+
+
+def test_july_random_rollout_vs_oracle_philox():
+    cfg = gmpe.make_config(num_envs=96, num_agents=10, world_size=4.0, episode_length=12, seed=123)
+    assert _rollout_vs_oracle(cfg, 30, seed=1) >= 96 * 2
+
+
+def test_july_tube_transit_vs_oracle():
+    cfg = gmpe.make_config(num_envs=64, num_agents=5, world_size=2.0, episode_length=40, seed=7)
+    _rollout_vs_oracle(cfg, 45, seed=2, shrink_world=True)
+
+
+def test_july_small_config_c1():
+    cfg = gmpe.make_config(num_envs=3, num_agents=3, world_size=4.0, episode_length=25, seed=5)
+    _rollout_vs_oracle(cfg, 30, seed=3)
+
+
+def test_navigation_graph_vs_oracle():
+    cfg = gmpe.make_config(scenario_name="navigation_graph", num_envs=64, num_agents=6, num_obstacles=3,
+                           num_walls=4, world_size=3.0, episode_length=20, seed=11)
+    assert _rollout_vs_oracle(cfg, 45, seed=4) >= 64
+
+
+def test_navigation_graph_c2_shape():
+    cfg = gmpe.make_config(scenario_name="navigation_graph", num_envs=32, num_agents=10, world_size=4.0,
+                           episode_length=25, seed=3)
+    _rollout_vs_oracle(cfg, 30, seed=5)
+
+
+def test_onehot_actions_match_index_actions():
+    import torch
+    cfg = gmpe.make_config(num_envs=16, num_agents=4, seed=9)
+    e1, e2 = _engine(cfg), _engine(cfg)
+    e1.reset(); e2.reset()
+    rng = np.random.RandomState(0)
+    for _ in range(5):
+        act = rng.randint(0, 25, (16, 4)).astype(np.int32)
+        onehot = np.eye(25, dtype=np.float32)[act]
+        o1 = e1.step(torch.as_tensor(act)); o2 = e2.step_onehot(torch.as_tensor(onehot))
+        for k in ("obs", "node_obs", "adj", "reward", "done"):
+            assert torch.equal(getattr(o1, k), getattr(o2, k)), k
+
+
+def test_compact_adj_is_the_broadcast():
+    import torch
+    cfg = gmpe.make_config(num_envs=8, num_agents=5, seed=2)
+    e1, e2 = _engine(cfg), _engine(cfg, adj_compact=True)
+    e1.reset(); e2.reset()
+    act = torch.zeros((8, 5), dtype=torch.int32)
+    o1, o2 = e1.step(act), e2.step(act)
+    assert torch.equal(o1.adj, o2.adj[:, None].expand_as(o1.adj))
+
+
+def test_sharded_equals_unsharded():
+    """Env ranges on different handles (GPUs) reproduce the single-handle run bit-for-bit (§8e)."""
+    import torch
+    N, A = 48, 6
+    full = _engine(gmpe.make_config(num_envs=N, num_agents=A, seed=77, episode_length=8))
+    parts = [_engine(gmpe.make_config(num_envs=N // 3, num_agents=A, seed=77, episode_length=8, env_id_base=g * (N // 3)))
+             for g in range(3)]
+    rng = np.random.RandomState(1)
+    full.reset(); [p.reset() for p in parts]
+    for t in range(20):
+        act = torch.as_tensor(rng.randint(0, 25, (N, A)).astype(np.int32))
+        of = full.step(act)
+        for g, p in enumerate(parts):
+            sl = slice(g * (N // 3), (g + 1) * (N // 3))
+            op = p.step(act[sl])
+            for k in ("obs", "node_obs", "adj", "reward", "done"):
+                assert torch.equal(getattr(of, k)[sl].cpu(), getattr(op, k).cpu()), (t, g, k)
+
+
+def test_edges_from_adj_kernel_bit_exact():
+    import torch
+    cfg = gmpe.make_config(num_envs=64, num_agents=10, seed=4)
+    eng = _engine(cfg)
+    eng.reset()
+    o = eng.step(torch.zeros((64, 10), dtype=torch.int32))
+    adj = o.adj.reshape(-1, 20, 20)
+    for dist, incl in ((1.0, False), (4.82802, True), (0.5, False)):
+        ei, ea, m = eng.edges_from_adj(adj, dist, inclusive=incl)
+        e_ref, w_ref = edges_numpy(_np(adj), np.float32(dist), incl)
+        assert m == e_ref.shape[1]
+        np.testing.assert_array_equal(_np(ei), e_ref)
+        np.testing.assert_array_equal(_np(ea), w_ref)
+
+
+def test_full_size_properties_c3():
+    """N=4096 x 10 agents (BASELINE config 3): size-independent invariants of the outputs."""
+    import torch
+    cfg = gmpe.make_config(num_envs=4096, num_agents=10, seed=1234)
+    eng = _engine(cfg)
+    eng.reset()
+    g = torch.Generator(device="cpu"); g.manual_seed(42)
+    for t in range(30):
+        act = torch.randint(0, 25, (4096, 10), generator=g, dtype=torch.int32)
+        o = eng.step(act)
+    adj = o.adj
+    assert torch.equal(adj, adj.transpose(-1, -2))                       # symmetric
+    assert (torch.diagonal(adj, dim1=-2, dim2=-1) == 0).all()             # zero diagonal
+    assert torch.equal(adj, adj[:, :1].expand_as(adj))                    # one matrix per env
+    r = o.reward
+    assert (r >= -20.0 - 1e-6).all() and (r <= 25.0 + 1e-6).all()        # clip(-4*cr, 5*gr)
+    node = o.node_obs
+    assert (node[:, :, :10, 7] == 0).all() and (node[:, :, 10:, 7] == 1).all()
+    # ego row of node_obs is zero relative position / velocity
+    idx = torch.arange(10, device=node.device)
+    assert (node[:, idx, idx, 0:4] == 0).all()
+    # adjacency entries equal the distance implied by node_obs rel_pos of ego (row = ego)
+    rel = node[:, idx, :, 2:4].double()
+    d = torch.sqrt((rel ** 2).sum(-1)).float()
+    row = adj[:, idx, idx, :]
+    live = row != 0
+    assert torch.allclose(row[live], d[live], atol=1e-5)
+    eng.check_errors()
