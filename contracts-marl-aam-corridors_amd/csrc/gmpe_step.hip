@@ -378,7 +378,7 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
                 double vx, vy; vel_of(c, l.n2[tid], l.n3[tid], vx, vy);
                 l.vnx[tid] = vx; l.vny[tid] = vy;
             }
-            if (tid == 0) l.flags[1] = __popcll(bal);
+            if (tid == 0) l.flags[1] = kinematic(c) ? __popcll(bal) : 0;   // draws consumed (DI reset_velocity draws none)
         }
         __syncthreads();
         const int n_new = l.flags[1];

@@ -165,7 +165,7 @@ def test_july_random_rollout_vs_oracle_philox():
 
 
 def test_july_tube_transit_vs_oracle():
-    cfg = gmpe.make_config(num_envs=64, num_agents=5, world_size=2.0, episode_length=40, seed=7)
+    cfg = gmpe.make_config(num_envs=64, num_agents=4, world_size=2.4, episode_length=40, seed=7)
     _rollout_vs_oracle(cfg, 45, seed=2, shrink_world=True)
 
 
