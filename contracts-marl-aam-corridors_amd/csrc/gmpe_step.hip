@@ -38,45 +38,73 @@ struct KParams {
     const uint8_t* mask;      // reset mask or nullptr
     int mode;
     int A, L, O, E, D;
+    int G;                    // envs per workgroup (G*A <= 64)
+    int ablate;               // debug: timing-only builds of the kernel skip parts (GMPE_ABLATE)
+    // magic multipliers for exact unsigned division by run-time constants (q < 2^22): floor(q/d) = umulhi(q, m)
+    uint32_t m_E, m_AE, m_EE, m_nq, m_2E, m_pe, m_AD, m_A, m_L, m_O;
 };
+__host__ __device__ inline uint32_t magic_of(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(0x100000000ull / d) + 1u; }
+__device__ __forceinline__ int fdiv(int q, int d, uint32_t m) { return d <= 1 ? q : (int)__umulhi((uint32_t)q, m); }
 
 // ---------------------------------------------------------------- LDS carve (dynamic, 16-B aligned)
+// A workgroup owns G consecutive environments (G*A <= 64: every agent of every env is one lane of
+// wave 0 for the sequential-semantics passes); all BLOCK threads share the O(E^2) distance pass and
+// the streaming stores. Arrays below hold G envs back to back.
 struct Lds {
-    double *ex, *ey;                  // [E]  entity positions (agents: post-integration)
-    double *s2, *s3;                  // [A]  theta/speed or vx/vy BEFORE this step's reward loop
-    double *n2, *n3;                  // [A]  ... AFTER it (reset_velocity on goal reach)
-    double *vox, *voy, *vnx, *vny;    // [A]  p_vel before / after
-    double *serr;                     // [A]  spacing error of this step (…_july.py:1168-1180)
-    double *rew;                      // [A]
-    double *tube;                     // [12]
-    int *s_old, *newf, *gt;           // [A]  status before, newly-reached flag, goal_tracker (final)
-    int *dtg_o, *dtg_n, *trq_o, *trq_n, *sv_o, *sv_n;   // [A] info counters old/new
-    int *flags;                       // [4]
-    float *obs;                       // [A*D] staging
-    float *M;                         // [E*E] masked distance matrix, fp32
+    double *ex, *ey;                  // [G][E]  entity positions (agents: post-integration)
+    double *s2, *s3;                  // [G][A]  theta/speed or vx/vy BEFORE this step's reward loop
+    double *n2, *n3;                  // [G][A]  ... AFTER it (reset_velocity on goal reach)
+    double *vox, *voy, *vnx, *vny;    // [G][A]  p_vel before / after
+    double *serr;                     // [G][A]  spacing error of this step (…_july.py:1168-1180)
+    double *rew;                      // [G][A]
+    double *tube;                     // [G][12]
+    double *Dm;                       // [G][A][E] fp64 agent->entity distances (rows of cached_dist_mag)
+    int *s_old, *newf, *gt;           // [G][A]  status before, newly-reached flag, goal_tracker (final)
+    int *dtg_o, *dtg_n, *trq_o, *trq_n, *sv_o, *sv_n;   // [G][A] info counters old/new
+    int *flags;                       // [G][4]  0: reset this env, 1: heading draws this step, 3: env active
+    float *obs;                       // [G][A*D] staging
+    float *M;                         // [G][E*E] masked distance matrix, fp32
 };
-__host__ __device__ inline size_t lds_bytes(int A, int E, int D) {
-    size_t d = (size_t)2 * E + 11 * A + 12;              // doubles
-    size_t i = (size_t)9 * A + 4;                        // ints
-    size_t f = (size_t)A * D + (size_t)E * E;            // floats
-    return d * 8 + ((i * 4 + 15) / 16) * 16 + ((f * 4 + 15) / 16) * 16 + 64;
+__host__ __device__ inline size_t lds_bytes(int G, int A, int E, int D) {
+    const size_t EE4 = ((size_t)E * E + 3) / 4 * 4, AD4 = ((size_t)A * D + 3) / 4 * 4;
+    size_t d = (size_t)G * (2 * E + 10 * A + 12 + (size_t)A * E);   // doubles
+    size_t f = (size_t)G * (EE4 + AD4);                             // floats
+    size_t i = (size_t)G * (9 * A + 4);                             // ints
+    return d * 8 + 16 + f * 4 + ((i * 4 + 15) / 16) * 16 + 32;
 }
-__device__ inline Lds carve(char* base, int A, int E, int D) {
+__device__ inline Lds carve(char* base, int G, int A, int E, int D) {
     Lds l;
     double* d = reinterpret_cast<double*>(base);
-    l.ex = d; d += E; l.ey = d; d += E;
-    l.s2 = d; d += A; l.s3 = d; d += A; l.n2 = d; d += A; l.n3 = d; d += A;
-    l.vox = d; d += A; l.voy = d; d += A; l.vnx = d; d += A; l.vny = d; d += A;
-    l.serr = d; d += A; l.rew = d; d += A; l.tube = d; d += 12;
+    l.ex = d; d += G * E; l.ey = d; d += G * E;
+    l.s2 = d; d += G * A; l.s3 = d; d += G * A; l.n2 = d; d += G * A; l.n3 = d; d += G * A;
+    l.vox = d; d += G * A; l.voy = d; d += G * A; l.vnx = d; d += G * A; l.vny = d; d += G * A;
+    l.serr = d; d += G * A; l.rew = d; d += G * A; l.tube = d; d += G * 12;
+    l.Dm = d; d += (size_t)G * A * E;
     if ((uintptr_t)d & 15) d += 1;
     float* f = reinterpret_cast<float*>(d);
-    l.M = f; f += ((size_t)E * E + 3) / 4 * 4;
-    l.obs = f; f += ((size_t)A * D + 3) / 4 * 4;
+    const size_t EE4 = ((size_t)E * E + 3) / 4 * 4, AD4 = ((size_t)A * D + 3) / 4 * 4;
+    l.M = f; f += (size_t)G * EE4;
+    l.obs = f; f += (size_t)G * AD4;
     int* i = reinterpret_cast<int*>(f);
-    l.s_old = i; i += A; l.newf = i; i += A; l.gt = i; i += A;
-    l.dtg_o = i; i += A; l.dtg_n = i; i += A; l.trq_o = i; i += A; l.trq_n = i; i += A;
-    l.sv_o = i; i += A; l.sv_n = i; i += A; l.flags = i;
+    l.s_old = i; i += G * A; l.newf = i; i += G * A; l.gt = i; i += G * A;
+    l.dtg_o = i; i += G * A; l.dtg_n = i; i += G * A; l.trq_o = i; i += G * A; l.trq_n = i; i += G * A;
+    l.sv_o = i; i += G * A; l.sv_n = i; i += G * A; l.flags = i;
     return l;
+}
+// view of env g inside the workgroup tile
+__device__ inline Lds env_view(const Lds& l, int g, int A, int E, int D) {
+    Lds v;
+    const size_t EE4 = ((size_t)E * E + 3) / 4 * 4, AD4 = ((size_t)A * D + 3) / 4 * 4;
+    v.ex = l.ex + g * E; v.ey = l.ey + g * E;
+    v.s2 = l.s2 + g * A; v.s3 = l.s3 + g * A; v.n2 = l.n2 + g * A; v.n3 = l.n3 + g * A;
+    v.vox = l.vox + g * A; v.voy = l.voy + g * A; v.vnx = l.vnx + g * A; v.vny = l.vny + g * A;
+    v.serr = l.serr + g * A; v.rew = l.rew + g * A; v.tube = l.tube + g * 12;
+    v.Dm = l.Dm + (size_t)g * A * E;
+    v.s_old = l.s_old + g * A; v.newf = l.newf + g * A; v.gt = l.gt + g * A;
+    v.dtg_o = l.dtg_o + g * A; v.dtg_n = l.dtg_n + g * A; v.trq_o = l.trq_o + g * A; v.trq_n = l.trq_n + g * A;
+    v.sv_o = l.sv_o + g * A; v.sv_n = l.sv_n + g * A; v.flags = l.flags + g * 4;
+    v.obs = l.obs + g * AD4; v.M = l.M + g * EE4;
+    return v;
 }
 
 __device__ __forceinline__ bool kinematic(const gmpe_config& c) { return c.dynamics != GMPE_DYN_DOUBLE_INTEGRATOR; }
@@ -86,11 +114,7 @@ __device__ __forceinline__ void vel_of(const gmpe_config& c, double a2, double a
     else { vx = a2; vy = a3; }                                       // core.py:191-193
 }
 
-// Scenario.is_obstacle_collision (…_july.py:864-890)
-__device__ inline bool obstacle_collision(const KParams& p, const Lds& l, double px, double py, double size) {
-    const int o0 = p.A + p.L;
-    for (int o = 0; o < p.O; ++o)
-        if (norm2(l.ex[o0 + o] - px, l.ey[o0 + o] - py) < 2.0 * (p.c.entity_size + size)) return true;
+__device__ __forceinline__ bool wall_band_hit(const KParams& p, double px, double py, double size) {
     for (int w = 0; w < p.c.num_walls; ++w) {
         const gmpe_wall& wl = p.c.walls[w];
         const double band = 1.5 * size;
@@ -100,6 +124,20 @@ __device__ inline bool obstacle_collision(const KParams& p, const Lds& l, double
     }
     return false;
 }
+// Scenario.is_obstacle_collision (…_july.py:864-890) at an arbitrary point (reset placement)
+__device__ inline bool obstacle_collision(const KParams& p, const Lds& l, double px, double py, double size) {
+    const int o0 = p.A + p.L;
+    for (int o = 0; o < p.O; ++o)
+        if (norm2(l.ex[o0 + o] - px, l.ey[o0 + o] - py) < 2.0 * (p.c.entity_size + size)) return true;
+    return wall_band_hit(p, px, py, size);
+}
+// same test for agent i at its current position, distances taken from the shared fp64 rows
+__device__ inline bool obstacle_collision_ego(const KParams& p, const Lds& l, int i) {
+    const double* row = l.Dm + (size_t)i * p.E + p.A + p.L;
+    for (int o = 0; o < p.O; ++o)
+        if (row[o] < 2.0 * (p.c.entity_size + p.c.entity_size)) return true;
+    return wall_band_hit(p, l.ex[i], l.ey[i], p.c.entity_size);
+}
 
 // _set_action (environment.py:336-475)
 __device__ inline void decode_action(const gmpe_config& c, int idx, double& u0, double& u1) {
@@ -107,14 +145,15 @@ __device__ inline void decode_action(const gmpe_config& c, int idx, double& u0, 
         if (c.n_actions == 5) {
             u0 = (idx == 1 ? 1.0 : 0.0) - (idx == 2 ? 1.0 : 0.0);
             u1 = (idx == 3 ? 1.0 : 0.0) - (idx == 4 ? 1.0 : 0.0);
-        } else {
-            const double m0[9] = {0, -1, -0.71, 0, 0.71, 1, 0.71, 0, -0.71};
-            const double m1[9] = {0, 0, -0.71, -1, -0.71, 0, 0.71, 1, 0.71};
-            u0 = m0[idx]; u1 = m1[idx];
+        } else {                                                     // action_map 382-392
+            const double d = 0.71;
+            u0 = (idx == 1 ? -1.0 : idx == 5 ? 1.0 : (idx == 2 || idx == 8) ? -d : (idx == 4 || idx == 6) ? d : 0.0);
+            u1 = (idx == 3 ? -1.0 : idx == 7 ? 1.0 : (idx == 2 || idx == 4) ? -d : (idx == 6 || idx == 8) ? d : 0.0);
         }
     } else {
         const int wi = idx / 5, ai = idx - wi * 5;
-        u0 = c.ang_rate_opt[wi]; u1 = c.accel_opt[ai];
+        u0 = wi == 0 ? c.ang_rate_opt[0] : wi == 1 ? c.ang_rate_opt[1] : wi == 2 ? c.ang_rate_opt[2] : wi == 3 ? c.ang_rate_opt[3] : c.ang_rate_opt[4];
+        u1 = ai == 0 ? c.accel_opt[0] : ai == 1 ? c.accel_opt[1] : ai == 2 ? c.accel_opt[2] : ai == 3 ? c.accel_opt[3] : c.accel_opt[4];
     }
     u0 *= c.sensitivity; u1 *= c.sensitivity;
 }
@@ -128,9 +167,10 @@ __device__ inline void write_obs(const KParams& p, const Lds& l, int i, double v
     o[0] = (float)px; o[1] = (float)py; o[2] = (float)vx; o[3] = (float)vy;
     o[4] = (float)gx; o[5] = (float)gy; o[6] = 0.0f; o[7] = (float)gx; o[8] = (float)gy;
     int b1 = -1, b2 = -1; double d1 = 0, d2 = 0;                   // stable two-smallest (1398-1417)
+    const double* row = l.Dm + (size_t)i * p.E;
     for (int k = 0; k < p.A; ++k) {
         if (k == i) continue;
-        const double d = norm2(l.ex[k] - px, l.ey[k] - py);
+        const double d = row[k];
         if (b1 < 0 || d < d1) { b2 = b1; d2 = d1; b1 = k; d1 = d; }
         else if (b2 < 0 || d < d2) { b2 = k; d2 = d; }
     }
@@ -229,36 +269,78 @@ __device__ void reset_world_serial(const KParams& p, const Lds& l, int n, int64_
     }
 }
 
+
+// fp64 agent->entity distance rows for every env of the tile (World.calculate_distances,
+// core.py:600-624: delta taken as pos[min]-pos[max], so the matrix is exactly symmetric).
+template <int BLOCK>
+__device__ __forceinline__ void distance_rows(const KParams& p, const Lds& l, int G, int tid, bool only_reset) {
+    const int A = p.A, E = p.E, AE = A * E;
+    for (int q = tid; q < G * AE; q += BLOCK) {
+        const int g = fdiv(q, AE, p.m_AE), rc = q - g * AE, r = fdiv(rc, E, p.m_E), cc = rc - r * E;
+        if (only_reset && !l.flags[g * 4 + 0]) continue;
+        double d = 0.0;
+        if (r != cc) {
+            const int a = r < cc ? r : cc, b = r < cc ? cc : r;
+            const double dx = l.ex[g * E + a] - l.ex[g * E + b], dy = l.ey[g * E + a] - l.ey[g * E + b];
+            d = sqrt(dx * dx + dy * dy);
+        }
+        l.Dm[q] = d;
+    }
+}
+
 // ---------------------------------------------------------------- the fused kernel
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int n = blockIdx.x, tid = threadIdx.x;
-    const int A = p.A, L = p.L, O = p.O, E = p.E, D = p.D;
+    const int tid = threadIdx.x;
+    const int A = p.A, L = p.L, O = p.O, E = p.E, D = p.D, G = p.G, N = p.c.num_envs;
     const gmpe_config& c = p.c;
-    if (p.mode == MODE_RESET && p.mask && !p.mask[n]) return;          // block-uniform
-    const Lds l = carve(smem, A, E, D);
-    const size_t na = (size_t)n * A + tid;
-    const bool ag = tid < A;                                            // agent lanes live in wave 0
+    const Lds l = carve(smem, G, A, E, D);
+    const int n0 = blockIdx.x * G;
+    const int Gv = min(G, N - n0);                                      // envs actually present in this tile
     const bool july = c.scenario == GMPE_SCENARIO_TUBE_JULY;
+    const bool step = p.mode == MODE_STEP;
+
+    // agent lane mapping: lane tid of wave 0 = (env g, agent i)
+    const int g = fdiv(tid, A, p.m_A), i = tid - g * A;
+    const int n = n0 + g;
+    bool ag = tid < Gv * A;
+    if (ag && !step && p.mask && !p.mask[n]) ag = false;               // explicit reset: masked-out env
+    const size_t na = (size_t)n * A + i;
+    const Lds v = env_view(l, ag ? g : 0, A, E, D);
+    const unsigned long long emask = ag ? ((A >= 64 ? ~0ull : ((1ull << A) - 1ull)) << (g * A)) : 0ull;
 
     // ---- per-agent registers
     int prev_phase = 0, phase_reached = 0, cooldown = 0;
     double p_dist = 0, tim = 0;
     int trq = -1, dtg = -1, dleft = -1, greached = -1, nac = 0, noc = 0, sv = 0, sic = 0, conf = 0;
     double gmt = 0;
-    int cur_step = p.s.current_step[n];
+    int cur_step = 0;
     int err = 0;
+    int64_t ctr0 = 0;
 
     // ---- 0. load state
-    if (tid < GMPE_TUBE_STRIDE) l.tube[tid] = p.s.tube[(size_t)n * GMPE_TUBE_STRIDE + tid];
-    for (int k = tid; k < L; k += BLOCK) { l.ex[A + k] = p.s.landmarks[((size_t)n * L + k) * 2]; l.ey[A + k] = p.s.landmarks[((size_t)n * L + k) * 2 + 1]; }
-    for (int k = tid; k < O; k += BLOCK) { l.ex[A + L + k] = p.s.obstacles[((size_t)n * O + k) * 2]; l.ey[A + L + k] = p.s.obstacles[((size_t)n * O + k) * 2 + 1]; }
+    for (int q = tid; q < Gv * GMPE_TUBE_STRIDE; q += BLOCK) l.tube[q] = p.s.tube[(size_t)n0 * GMPE_TUBE_STRIDE + q];
+    for (int q = tid; q < Gv * L; q += BLOCK) {
+        const int gg = q / L, k = q - gg * L;
+        l.ex[gg * E + A + k] = p.s.landmarks[((size_t)n0 * L + q) * 2]; l.ey[gg * E + A + k] = p.s.landmarks[((size_t)n0 * L + q) * 2 + 1];
+    }
+    for (int q = tid; q < Gv * O; q += BLOCK) {
+        const int gg = q / O, k = q - gg * O;
+        l.ex[gg * E + A + L + k] = p.s.obstacles[((size_t)n0 * O + q) * 2]; l.ey[gg * E + A + L + k] = p.s.obstacles[((size_t)n0 * O + q) * 2 + 1];
+    }
+    if (tid < G) {
+        const int nn = n0 + tid;
+        const bool active = nn < N && (step || !p.mask || p.mask[nn]);
+        l.flags[tid * 4 + 0] = (!step && active); l.flags[tid * 4 + 1] = 0; l.flags[tid * 4 + 2] = 0; l.flags[tid * 4 + 3] = active;
+    }
     if (ag) {
         prev_phase = p.s.prev_phase[na];
-        if (p.mode == MODE_STEP) {
-            l.ex[tid] = p.s.x[na]; l.ey[tid] = p.s.y[na]; l.s2[tid] = p.s.s2[na]; l.s3[tid] = p.s.s3[na];
-            l.s_old[tid] = p.s.status[na]; l.gt[tid] = p.s.goal_tracker[na];
+        cur_step = p.s.current_step[n];
+        ctr0 = p.s.rng_ctr[n];
+        if (step) {
+            v.ex[i] = p.s.x[na]; v.ey[i] = p.s.y[na]; v.s2[i] = p.s.s2[na]; v.s3[i] = p.s.s3[na];
+            v.s_old[i] = p.s.status[na]; v.gt[i] = p.s.goal_tracker[na];
             phase_reached = p.s.phase_reached[na]; cooldown = p.s.cooldown[na];
             p_dist = p.s.p_dist[na]; tim = p.s.time[na];
             trq = p.s.times_required[na]; dtg = p.s.dists_to_goal[na]; dleft = p.s.dist_left[na];
@@ -267,13 +349,13 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
             gmt = p.s.goal_min_time[na];
         }
     }
-    if (tid == 0) l.flags[0] = (p.mode == MODE_RESET);
     __syncthreads();
 
     int ph1 = 0;
-    if (p.mode == MODE_STEP) {
+    if (step) {
         cur_step += 1;
         // ---- 1. action decode + dynamics
+        if (!kinematic(c)) { distance_rows<BLOCK>(p, l, Gv, tid, false); __syncthreads(); }   // pre-move distances for the contact forces
         double nx = 0, ny = 0, nv2 = 0, nv3 = 0;
         if (ag) {
             int idx;
@@ -285,9 +367,9 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
             }
             idx = idx < 0 ? 0 : (idx >= c.n_actions ? c.n_actions - 1 : idx);
             double u0, u1; decode_action(c, idx, u0, u1);
-            nx = l.ex[tid]; ny = l.ey[tid]; nv2 = l.s2[tid]; nv3 = l.s3[tid];
+            nx = v.ex[i]; ny = v.ey[i]; nv2 = v.s2[i]; nv3 = v.s3[i];
             if (kinematic(c)) {
-                if (!l.s_old[tid]) {                                    // update_agent_state core.py:819-826
+                if (!v.s_old[i]) {                                      // update_agent_state core.py:819-826
                     const double dt = c.dt, th0 = nv2, v0 = nv3;
                     const double th1 = th0 + u0 * dt, v1 = v0 + u1 * dt;
                     if (u0 != 0.0) {
@@ -298,27 +380,29 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
                         const double d = (v0 + 0.5 * u1 * dt) * dt;
                         nx += d * cos(th0); ny += d * sin(th0);
                     }
-                    double v = v1;
-                    if (v > c.v_max) v = c.v_max;
-                    if (v < c.v_min) v = c.v_min;
-                    nv2 = th1; nv3 = v;
-                    p_dist += v * dt; tim += dt;
+                    double vv = v1;
+                    if (vv > c.v_max) vv = c.v_max;
+                    if (vv < c.v_min) vv = c.v_min;
+                    nv2 = th1; nv3 = vv;
+                    p_dist += vv * dt; tim += dt;
                 }
             } else {
                 // force path core.py:766-845, 872-964: accumulate in the reference's order for this agent:
                 // other entities by ascending index (as side b below its own index, side a above), then walls.
                 double Fx = 1.0 * u0, Fy = 1.0 * u1;
                 const double pax = nx, pay = ny;
+                const double* row = v.Dm + (size_t)i * E;
+                const bool ego_done = v.s_old[i] != 0;
                 for (int k = 0; k < E; ++k) {
-                    if (k == tid) continue;
-                    if (k >= A && k < A + L) continue;                  // landmarks: collide=False
-                    const bool ego_is_b = k < tid;
-                    const double dx = ego_is_b ? l.ex[k] - pax : pax - l.ex[k];
-                    const double dy = ego_is_b ? l.ey[k] - pay : pay - l.ey[k];
-                    const double dist = sqrt(dx * dx + dy * dy);
+                    if (k == i) continue;
+                    if (k >= A && k < A + L) { k = A + L - 1; continue; }   // landmarks: collide=False
+                    const double dist = row[k];
                     const double z = -(dist - c.sep_dist) / c.contact_margin;
                     if (z < -50.0) continue;                            // softplus < 1e-21: below one ulp of the sum
-                    if (k < A && l.s_old[tid]) continue;                // done side gets no force (899-900)
+                    if (k < A && ego_done) continue;                    // done side gets no force (899-900)
+                    const bool ego_is_b = k < i;
+                    const double dx = ego_is_b ? v.ex[k] - pax : pax - v.ex[k];
+                    const double dy = ego_is_b ? v.ey[k] - pay : pay - v.ey[k];
                     const double pen = logaddexp0(z) * c.contact_margin;
                     const double fx = c.contact_force * dx / dist * pen, fy = c.contact_force * dy / dist * pen;
                     if (ego_is_b) { Fx = -fx + Fx; Fy = -fy + Fy; } else { Fx = fx + Fx; Fy = fy + Fy; }
@@ -331,7 +415,7 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
                 vx += (Fx / 1.0) * c.dt; vy += (Fy / 1.0) * c.dt;
                 if (c.max_speed > 0) {
                     const double sp = sqrt(vx * vx + vy * vy);
-                    if (sp > c.max_speed) { const double q = sqrt(vx * vx + vy * vy); vx = vx / q * c.max_speed; vy = vy / q * c.max_speed; }
+                    if (sp > c.max_speed) { vx = vx / sp * c.max_speed; vy = vy / sp * c.max_speed; }
                 }
                 nv2 = vx; nv3 = vy;
                 nx += vx * c.dt; ny += vy * c.dt;
@@ -340,7 +424,9 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
             }
         }
         __syncthreads();                                                // all lanes have read the old positions
-        if (ag) { l.ex[tid] = nx; l.ey[tid] = ny; l.s2[tid] = nv2; l.s3[tid] = nv3; }
+        if (ag) { v.ex[i] = nx; v.ey[i] = ny; v.s2[i] = nv2; v.s3[i] = nv3; }
+        __syncthreads();
+        distance_rows<BLOCK>(p, l, Gv, tid, false);                    // post-move rows: obs, reward, info, adj all read these
         __syncthreads();
 
         // ---- 2. phase FSM + who newly reaches the goal (depends only on own data: SURVEY §8a)
@@ -348,89 +434,85 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
         bool goal_branch = true;
         double dgoal = 0;
         if (ag) {
-            const double px = l.ex[tid], py = l.ey[tid];
-            double vx, vy; vel_of(c, l.s2[tid], l.s3[tid], vx, vy);
-            l.vox[tid] = vx; l.voy[tid] = vy;
+            const double px = v.ex[i], py = v.ey[i];
+            double vx, vy; vel_of(c, v.s2[i], v.s3[i], vx, vy);
+            v.vox[i] = vx; v.voy[i] = vy;
             if (july) {
-                ph1 = phase_eval(l.tube, px, py, prev_phase, prevA);     // observation's call (:1447)
+                ph1 = phase_eval(v.tube, px, py, prev_phase, prevA);     // observation's call (:1447)
                 if (cooldown > 0) cooldown -= 1;
                 int prevB;
-                cp = phase_eval(l.tube, px, py, prevA, prevB);           // reward's call (:1113)
+                cp = phase_eval(v.tube, px, py, prevA, prevB);           // reward's call (:1113)
                 if (cooldown > 0) cooldown -= 1;
                 prevA = prevB;
                 goal_branch = (cp == 2 && phase_reached != 0);
             }
-            dgoal = norm2(px - l.ex[A + tid], py - l.ey[A + tid]);
-            const bool nf = goal_branch && dgoal < c.goal_thresh && !l.s_old[tid];
-            l.newf[tid] = nf;
+            dgoal = v.Dm[(size_t)i * E + A + i];
+            v.newf[i] = goal_branch && dgoal < c.goal_thresh && !v.s_old[i];
         }
-        // rank of each newly-reached agent among them: the heading re-draws follow agent order (core.py:328)
-        int64_t ctr0 = p.s.rng_ctr[n];
+        // rank of each newly-reached agent among its env's: heading re-draws follow agent order (core.py:328)
         if (tid < 64) {
-            const unsigned long long bal = __ballot(ag && l.newf[tid]);
+            const unsigned long long bal = __ballot(ag && v.newf[i]);
             if (ag) {
-                if (l.newf[tid]) {
-                    const int rank = __popcll(bal & ((1ull << tid) - 1ull));
-                    if (kinematic(c)) { l.n2[tid] = 0.0 + (2 * M_PI - 0.0) * draw_at(c, p.s, n, ctr0 + rank, err); l.n3[tid] = c.v_min; }
-                    else { l.n2[tid] = 0.0; l.n3[tid] = 0.0; }
-                    l.gt[tid] = tid;
-                } else { l.n2[tid] = l.s2[tid]; l.n3[tid] = l.s3[tid]; }
-                double vx, vy; vel_of(c, l.n2[tid], l.n3[tid], vx, vy);
-                l.vnx[tid] = vx; l.vny[tid] = vy;
+                if (v.newf[i]) {
+                    const int rank = __popcll(bal & emask & ((1ull << tid) - 1ull));
+                    if (kinematic(c)) { v.n2[i] = 0.0 + (2 * M_PI - 0.0) * draw_at(c, p.s, n, ctr0 + rank, err); v.n3[i] = c.v_min; }
+                    else { v.n2[i] = 0.0; v.n3[i] = 0.0; }
+                    v.gt[i] = i;
+                } else { v.n2[i] = v.s2[i]; v.n3[i] = v.s3[i]; }
+                double vx, vy; vel_of(c, v.n2[i], v.n3[i], vx, vy);
+                v.vnx[i] = vx; v.vny[i] = vy;
+                if (i == 0) v.flags[1] = kinematic(c) ? __popcll(bal & emask) : 0;   // draws consumed (DI reset_velocity draws none)
             }
-            if (tid == 0) l.flags[1] = kinematic(c) ? __popcll(bal) : 0;   // draws consumed (DI reset_velocity draws none)
         }
         __syncthreads();
-        const int n_new = l.flags[1];
 
         // ---- 3. obs, reward, done (ego i sees agent k done iff s_old[k] || (new[k] && k < i))
         double rew = 0; bool done = false;
         if (ag) {
-            const int i = tid;
-            const double px = l.ex[i], py = l.ey[i];
-            write_obs(p, l, i, l.vox[i], l.voy[i], ph1);
+            const double px = v.ex[i], py = v.ey[i];
+            const double* row = v.Dm + (size_t)i * E;
+            write_obs(p, v, i, v.vox[i], v.voy[i], ph1);
             // collision block (…_july.py:1117-1124)
-            if (!l.s_old[i])
+            if (!v.s_old[i])
                 for (int a = 0; a < A; ++a) {
                     if (a == i) continue;
-                    const bool a_done = l.s_old[a] || (l.newf[a] && a < i);
-                    if (a_done) continue;
-                    if (norm2(l.ex[a] - px, l.ey[a] - py) < c.sep_dist) rew -= c.collision_rew * 4;
+                    const bool a_done = v.s_old[a] || (v.newf[a] && a < i);
+                    if (!a_done && row[a] < c.sep_dist) rew -= c.collision_rew * 4;
                 }
-            if (obstacle_collision(p, l, px, py, c.entity_size)) rew -= c.collision_rew * 3;
+            const bool obst_hit = obstacle_collision_ego(p, v, i);
+            if (obst_hit) rew -= c.collision_rew * 3;
             double serr = 0;
             if (july) {
-                const double tdx = l.tube[T_EXX] - l.tube[T_ENTX], tdy = l.tube[T_EXY] - l.tube[T_ENTY];
+                const double tdx = v.tube[T_EXX] - v.tube[T_ENTX], tdy = v.tube[T_EXY] - v.tube[T_ENTY];
                 const double tlen = sqrt(tdx * tdx + tdy * tdy);
-                const double hx = cos(l.s2[i]), hy = sin(l.s2[i]);
-                int front = -1, back = -1; double fproj = 0, bproj = 0;
-                for (int k = 0; k < A; ++k) {
-                    if (k == i) continue;
-                    const double proj = (l.ex[k] - px) * hx + (l.ey[k] - py) * hy;
-                    if (proj > 0) { if (front < 0 || proj < fproj) { front = k; fproj = proj; } }
-                    else { if (back < 0 || proj > bproj) { back = k; bproj = proj; } }
-                }
-                // prevA here is previous_phase as the reward sees it (after both phase calls)
                 if (cp == 2 && cp > prevA + 1) rew -= c.goal_rew * 3;
                 const double ux = tdx / tlen, uy = tdy / tlen;
-                const double qx = px - l.tube[T_ENTX], qy = py - l.tube[T_ENTY];
+                const double qx = px - v.tube[T_ENTX], qy = py - v.tube[T_ENTY];
                 const double proj = qx * ux + qy * uy;
                 const double edist = norm2(qx - proj * tdx, qy - proj * tdy);      // un-normalised (:1154)
                 if (cp == prevA + 1 && phase_reached == cp - 1) {
                     if (cp == 1 && 0 <= proj && proj < 0.1 * tlen && edist < 0.2 * tlen) rew += c.goal_rew * 3;
                     else if (cp == 2) rew += c.goal_rew * 3;
                 }
-                if (cp == 0) rew -= norm2(l.tube[T_ENTX] - px, l.tube[T_ENTY] - py);
+                if (cp == 0) rew -= norm2(v.tube[T_ENTX] - px, v.tube[T_ENTY] - py);
                 else if (cp == 1) {
-                    if (front >= 0) { const double df = norm2(l.ex[front] - px, l.ey[front] - py) - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
-                    if (back >= 0) { const double df = norm2(l.ex[back] - px, l.ey[back] - py) - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
+                    const double hx = cos(v.s2[i]), hy = sin(v.s2[i]);
+                    int front = -1, back = -1; double fproj = 0, bproj = 0;
+                    for (int k = 0; k < A; ++k) {                       // 1136-1143, first wins ties
+                        if (k == i) continue;
+                        const double pj = (v.ex[k] - px) * hx + (v.ey[k] - py) * hy;
+                        if (pj > 0) { if (front < 0 || pj < fproj) { front = k; fproj = pj; } }
+                        else { if (back < 0 || pj > bproj) { back = k; bproj = pj; } }
+                    }
+                    if (front >= 0) { const double df = row[front] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
+                    if (back >= 0) { const double df = row[back] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
                     if (serr > 0) sv += 1;
                     rew -= serr * c.formation_rew;
-                    rew -= norm2(l.tube[T_EXX] - px, l.tube[T_EXY] - py);
+                    rew -= norm2(v.tube[T_EXX] - px, v.tube[T_EXY] - py);
                     sic += 1;
                 } else if (cp == 2 && phase_reached == 0) cp = 0;
                 else {
-                    if (dgoal < c.goal_thresh) { if (l.newf[i]) rew += c.goal_rew * 5; }
+                    if (dgoal < c.goal_thresh) { if (v.newf[i]) rew += c.goal_rew * 5; }
                     else rew -= dgoal;
                 }
                 if (phase_reached == 1 && cp == 0) conf += 1;
@@ -439,20 +521,20 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
                 if (cp < phase_reached) rew -= c.collision_rew;
                 prev_phase = cp;
             } else {
-                if (dgoal < c.goal_thresh) { if (l.newf[i]) rew += c.goal_rew * 5; }
+                if (dgoal < c.goal_thresh) { if (v.newf[i]) rew += c.goal_rew * 5; }
                 else rew -= dgoal;
             }
             rew = clipd(rew, -4 * c.collision_rew, c.goal_rew * 5);
             rew = clipd(rew, c.min_reward, c.max_reward);
-            l.serr[i] = serr; l.rew[i] = rew;
-            const bool st = l.s_old[i] || l.newf[i];
+            v.serr[i] = serr; v.rew[i] = rew;
+            const bool st = v.s_old[i] || v.newf[i];
             done = st || cur_step >= c.episode_length;                   // _get_done environment.py:264-271
 
             // ---- info counters that depend on own data only (…_july.py:744-773)
-            l.dtg_o[i] = dtg; l.trq_o[i] = trq; l.sv_o[i] = l.sv_n[i] = 0;
+            v.dtg_o[i] = dtg; v.trq_o[i] = trq;
             int nearest = 0; double dmin = 0;
             for (int q = 0; q < L; ++q) {
-                const double d = norm2(px - l.ex[A + q], py - l.ey[A + q]);
+                const double d = row[A + q];
                 if (q == 0 || d < dmin) { dmin = d; nearest = q; }
             }
             const double thr = c.goal_thresh;
@@ -462,40 +544,46 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
             if (trq == -1) { dtg = (int)p_dist; dleft = (int)dmin; }
             if (dmin > thr && trq != -1) { dtg = (int)p_dist; trq = tnow; dleft = (int)dmin; }
             if (dmin < thr && nearest == greached) { dleft = (int)dmin; greached = nearest; }
-            l.dtg_n[i] = dtg; l.trq_n[i] = trq;
-            l.sv_n[i] = sv; l.sv_o[i] = sv - (serr > 0 ? 1 : 0);
+            v.dtg_n[i] = dtg; v.trq_n[i] = trq;
+            v.sv_n[i] = sv; v.sv_o[i] = sv - (serr > 0 ? 1 : 0);
+            if (obst_hit) noc += 1;                                      // info_callback :778-779
+        }
+        // all agents of an env done -> the worker resets it (env_wrappers.py:865-870)
+        bool all_done = false;
+        if (tid < 64) {
+            const unsigned long long dbal = __ballot(ag && done);
+            all_done = ag && ((dbal & emask) == emask);
+            if (ag && i == 0) v.flags[0] = all_done;
         }
         __syncthreads();
 
         // ---- 4. info (sequential view: agents j<=i already updated, j>i not yet), outputs, write-back
-        const bool all_done = __syncthreads_and(ag ? (int)done : 1) != 0;
         if (ag) {
-            const int i = tid;
-            const double px = l.ex[i], py = l.ey[i];
-            if (obstacle_collision(p, l, px, py, c.entity_size)) noc += 1;
-            const bool me_done = l.s_old[i] || l.newf[i];
+            const double* row = v.Dm + (size_t)i * E;
+            const bool me_done = v.s_old[i] || v.newf[i];
             if (!me_done)
                 for (int a = 0; a < A; ++a) {
                     if (a == i) continue;
-                    const bool a_done = l.s_old[a] || (l.newf[a] && a <= i);
-                    if (!a_done && norm2(px - l.ex[a], py - l.ey[a]) < c.sep_dist) nac += 1;
+                    const bool a_done = v.s_old[a] || (v.newf[a] && a <= i);
+                    if (!a_done && row[a] < c.sep_dist) nac += 1;
                 }
             double rsum = 0;
-            if (c.collaborative) for (int a = 0; a < A; ++a) rsum += l.rew[a];
+            if (c.collaborative) for (int a = 0; a < A; ++a) rsum += v.rew[a];
             if (p.o.reward) p.o.reward[na] = (float)(c.collaborative ? rsum : rew);
             if (p.o.done) p.o.done[na] = done ? 1 : 0;
+            const double dsp0 = p.s.delta_spacing[n];
             if (p.o.info) {
-                double dm = 0, tm = 0, svsum = 0, dsp = p.s.delta_spacing[n];
+                double dm = 0, tm = 0, svsum = 0, dsp = dsp0;
                 for (int a = 0; a < A; ++a) {
-                    dm += a <= i ? l.dtg_n[a] : l.dtg_o[a];
-                    tm += a <= i ? l.trq_n[a] : l.trq_o[a];
-                    svsum += a <= i ? l.sv_n[a] : l.sv_o[a];
+                    dm += a <= i ? v.dtg_n[a] : v.dtg_o[a];
+                    tm += a <= i ? v.trq_n[a] : v.trq_o[a];
+                    svsum += a <= i ? v.sv_n[a] : v.sv_o[a];
                 }
-                for (int a = 0; a <= i; ++a) dsp += l.serr[a];          // same order as the list append
+                for (int a = 0; a <= i; ++a) dsp += v.serr[a];          // same order as the list append
                 dm /= A; tm /= A;
                 double dv = 0, tv = 0;
                 for (int a = 0; a < A; ++a) {
-                    const double pq = (a <= i ? l.dtg_n[a] : l.dtg_o[a]) - dm, qq = (a <= i ? l.trq_n[a] : l.trq_o[a]) - tm;
+                    const double pq = (a <= i ? v.dtg_n[a] : v.dtg_o[a]) - dm, qq = (a <= i ? v.trq_n[a] : v.trq_o[a]) - tm;
                     dv += pq * pq; tv += qq * qq;
                 }
                 const double ds = sqrt(dv / A), ts = sqrt(tv / A);
@@ -508,53 +596,50 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
                 o[15] = (float)((double)sv / (sic != 0 ? sic : 1));
                 o[16] = (float)gmt;
             }
-        }
-        if (tid == 0) {
-            if (!all_done) {
-                double dsp = p.s.delta_spacing[n];
-                for (int a = 0; a < A; ++a) dsp += l.serr[a];
-                p.s.delta_spacing[n] = dsp;
-                p.s.rng_ctr[n] = ctr0 + n_new;
-                p.s.current_step[n] = cur_step;
+            if (!all_done) {                                            // persist the stepped state
+                if (i == 0) {
+                    double dsp = dsp0;
+                    for (int a = 0; a < A; ++a) dsp += v.serr[a];
+                    p.s.delta_spacing[n] = dsp;
+                    p.s.rng_ctr[n] = ctr0 + v.flags[1];
+                    p.s.current_step[n] = cur_step;
+                }
+                p.s.x[na] = v.ex[i]; p.s.y[na] = v.ey[i]; p.s.s2[na] = v.n2[i]; p.s.s3[na] = v.n3[i];
+                p.s.status[na] = (uint8_t)(v.s_old[i] || v.newf[i]);
+                p.s.prev_phase[na] = prev_phase; p.s.phase_reached[na] = phase_reached; p.s.cooldown[na] = cooldown;
+                p.s.goal_tracker[na] = v.gt[i]; p.s.p_dist[na] = p_dist; p.s.time[na] = tim;
+                p.s.times_required[na] = trq; p.s.dists_to_goal[na] = dtg; p.s.dist_left[na] = dleft;
+                p.s.goal_reached[na] = greached; p.s.n_agent_coll[na] = nac; p.s.n_obst_coll[na] = noc;
+                p.s.spacing_viol[na] = sv; p.s.steps_in_corr[na] = sic; p.s.conformance[na] = conf;
             }
-            l.flags[0] = all_done;
-        }
-        if (ag && !all_done) {                                          // persist the stepped state
-            p.s.x[na] = l.ex[tid]; p.s.y[na] = l.ey[tid]; p.s.s2[na] = l.n2[tid]; p.s.s3[na] = l.n3[tid];
-            p.s.status[na] = (uint8_t)(l.s_old[tid] || l.newf[tid]);
-            p.s.prev_phase[na] = prev_phase; p.s.phase_reached[na] = phase_reached; p.s.cooldown[na] = cooldown;
-            p.s.goal_tracker[na] = l.gt[tid]; p.s.p_dist[na] = p_dist; p.s.time[na] = tim;
-            p.s.times_required[na] = trq; p.s.dists_to_goal[na] = dtg; p.s.dist_left[na] = dleft;
-            p.s.goal_reached[na] = greached; p.s.n_agent_coll[na] = nac; p.s.n_obst_coll[na] = noc;
-            p.s.spacing_viol[na] = sv; p.s.steps_in_corr[na] = sic; p.s.conformance[na] = conf;
         }
         __syncthreads();
     }
 
-    // ---- 5. reset (explicit, or the worker's auto-reset when every agent is done)
-    const bool do_reset = l.flags[0] != 0;                               // block-uniform
-    if (do_reset) {
-        if (tid == 0) {
-            int64_t ctr = p.s.rng_ctr[n];
-            if (p.mode == MODE_STEP) ctr += l.flags[1];                  // this step's heading re-draws come first
-            reset_world_serial(p, l, n, ctr, err);
+    // ---- 5. reset (explicit, or the worker's auto-reset when every agent of the env is done)
+    int any_reset = 0;
+    for (int gg = 0; gg < Gv; ++gg) any_reset |= l.flags[gg * 4 + 0];     // block-uniform
+    if (any_reset) {
+        const bool mine = ag && v.flags[0];
+        if (mine && i == 0) {                                             // one lane per resetting env
+            int64_t ctr = ctr0 + (step ? v.flags[1] : 0);                // this step's heading re-draws come first
+            reset_world_serial(p, v, n, ctr, err);
             p.s.rng_ctr[n] = ctr;
             p.s.current_step[n] = 0;
             p.s.delta_spacing[n] = 0.0;
         }
         __syncthreads();
-        if (ag) {
-            const int i = tid;
-            l.s2[i] = l.n2[i]; l.s3[i] = l.n3[i];
-            double vx, vy; vel_of(c, l.n2[i], l.n3[i], vx, vy);
-            l.vox[i] = l.vnx[i] = vx; l.voy[i] = l.vny[i] = vy;
-            l.s_old[i] = 0; l.newf[i] = 0; l.gt[i] = -1;
+        if (mine) {
+            v.s2[i] = v.n2[i]; v.s3[i] = v.n3[i];
+            double vx, vy; vel_of(c, v.n2[i], v.n3[i], vx, vy);
+            v.vox[i] = v.vnx[i] = vx; v.voy[i] = v.vny[i] = vy;
+            v.s_old[i] = 0; v.newf[i] = 0; v.gt[i] = -1;
             int prevA = prev_phase, ph = 0;
-            if (july) ph = phase_eval(l.tube, l.ex[i], l.ey[i], prev_phase, prevA);   // reset-time observation (:1447)
+            if (july) ph = phase_eval(v.tube, v.ex[i], v.ey[i], prev_phase, prevA);   // reset-time observation (:1447)
             prev_phase = prevA;
-            const double dx = l.ex[i] - l.ex[A + i], dy = l.ey[i] - l.ey[A + i];
+            const double dx = v.ex[i] - v.ex[A + i], dy = v.ey[i] - v.ey[A + i];
             gmt = c.max_speed > 0 ? sqrt(dx * dx + dy * dy) / c.max_speed : 0.0;
-            p.s.x[na] = l.ex[i]; p.s.y[na] = l.ey[i]; p.s.s2[na] = l.n2[i]; p.s.s3[na] = l.n3[i];
+            p.s.x[na] = v.ex[i]; p.s.y[na] = v.ey[i]; p.s.s2[na] = v.n2[i]; p.s.s3[na] = v.n3[i];
             p.s.status[na] = 0; p.s.prev_phase[na] = prev_phase; p.s.phase_reached[na] = 0; p.s.cooldown[na] = 0;
             p.s.goal_tracker[na] = -1; p.s.p_dist[na] = 0.0; p.s.time[na] = 0.0;
             p.s.times_required[na] = -1; p.s.dists_to_goal[na] = -1; p.s.dist_left[na] = -1;
@@ -564,76 +649,109 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
             ph1 = ph;
         }
         __syncthreads();                                                // positions of all agents final
-        if (ag) write_obs(p, l, tid, l.vox[tid], l.voy[tid], ph1);
+        distance_rows<BLOCK>(p, l, Gv, tid, true);
+        __syncthreads();
+        if (mine) write_obs(p, v, i, v.vox[i], v.voy[i], ph1);
     }
-    if (err) atomicOr(&p.s.error_flags[n], err);
+    if (ag && err) atomicOr(&p.s.error_flags[n], err);
     __syncthreads();
 
+    const int abl = p.ablate;
     // ---- 6. masked distance matrix (calculate_distances core.py:600-624 + mask …_july.py:1627-1648), fp32 in LDS
-    for (int q = tid; q < E * E; q += BLOCK) {
-        const int r = q / E, cc = q - r * E;
+    const int EE = E * E, EE4 = (EE + 3) / 4 * 4, AD4 = (A * D + 3) / 4 * 4;
+    if (!(abl & 4))
+    for (int q = tid; q < Gv * EE; q += BLOCK) {
+        const int gg = fdiv(q, EE, p.m_EE), rc = q - gg * EE, r = fdiv(rc, E, p.m_E), cc = rc - r * E;
+        const int ab = gg * A, eb = gg * E;
         double d = 0.0;
         if (r != cc) {
-            const int a = r < cc ? r : cc, b = r < cc ? cc : r;       // upper-triangle delta, mirrored
-            const double dx = l.ex[a] - l.ex[b], dy = l.ey[a] - l.ey[b];
-            d = sqrt(dx * dx + dy * dy);
+            if (r < A) d = l.Dm[(size_t)gg * A * E + r * E + cc];
+            else if (cc < A) d = l.Dm[(size_t)gg * A * E + cc * E + r];
+            else {
+                const int a = r < cc ? r : cc, b = r < cc ? cc : r;
+                const double dx = l.ex[eb + a] - l.ex[eb + b], dy = l.ey[eb + a] - l.ey[eb + b];
+                d = sqrt(dx * dx + dy * dy);
+            }
             bool off = false;
-            if (r < A) off |= (l.s_old[r] || l.newf[r]) != 0;
-            if (cc < A) off |= (l.s_old[cc] || l.newf[cc]) != 0;
-            if (r >= A && r < A + L) off |= (r - A < A && l.gt[r - A] == r - A);
-            if (cc >= A && cc < A + L) off |= (cc - A < A && l.gt[cc - A] == cc - A);
+            if (r < A) off |= (l.s_old[ab + r] | l.newf[ab + r]) != 0;
+            if (cc < A) off |= (l.s_old[ab + cc] | l.newf[ab + cc]) != 0;
+            if (r >= A && r < A + L) off |= (r - A < A && l.gt[ab + r - A] == r - A);
+            if (cc >= A && cc < A + L) off |= (cc - A < A && l.gt[ab + cc - A] == cc - A);
             if (off) d = 0.0;
         }
-        l.M[q] = (float)d;
+        l.M[(size_t)gg * EE4 + rc] = (float)d;
     }
     __syncthreads();
 
     // ---- 7. stream the observations out (16-byte stores wherever the row length allows)
-    const int EE = E * E;
-    if (p.o.adj) {
+    if (p.o.adj && !(abl & 1)) {
+        const bool vec = (EE & 3) == 0;
         if (p.o.adj_compact) {
-            float* dst = p.o.adj + (size_t)n * EE;
-            if ((EE & 3) == 0) for (int q = tid; q < EE / 4; q += BLOCK) reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(l.M)[q];
-            else for (int q = tid; q < EE; q += BLOCK) dst[q] = l.M[q];
-        } else {
-            float* dst = p.o.adj + (size_t)n * A * EE;
-            if ((EE & 3) == 0) {
+            float* dst = p.o.adj + (size_t)n0 * EE;
+            if (vec) {
                 const int nq = EE / 4;
-                for (int q = tid; q < A * nq; q += BLOCK) {
-                    const int m = q % nq;                                // same E×E for every ego
-                    reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(l.M)[m];
+                for (int q = tid; q < Gv * nq; q += BLOCK) {
+                    const int gg = fdiv(q, nq, p.m_nq), m = q - gg * nq;
+                    if (l.flags[gg * 4 + 3]) reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(l.M + (size_t)gg * EE4)[m];
                 }
-            } else for (int q = tid; q < A * EE; q += BLOCK) dst[q] = l.M[q % EE];
+            } else for (int q = tid; q < Gv * EE; q += BLOCK) { const int gg = q / EE; if (l.flags[gg * 4 + 3]) dst[q] = l.M[(size_t)gg * EE4 + (q - gg * EE)]; }
+        } else {
+            float* dst = p.o.adj + (size_t)n0 * A * EE;
+            if (vec) {
+                const int nq = EE / 4;
+                // each lane keeps one float4 of the env's matrix and stores it to the A ego copies
+                for (int q = tid; q < Gv * nq; q += BLOCK) {
+                    const int gg = fdiv(q, nq, p.m_nq), m = q - gg * nq;
+                    if (!l.flags[gg * 4 + 3]) continue;
+                    const float4 val = reinterpret_cast<const float4*>(l.M + (size_t)gg * EE4)[m];
+                    float4* d4 = reinterpret_cast<float4*>(dst) + (size_t)gg * A * nq + m;
+                    for (int a = 0; a < A; ++a) d4[(size_t)a * nq] = val;
+                }
+            } else {
+                for (int q = tid; q < Gv * A * EE; q += BLOCK) {
+                    const int gg = q / (A * EE), rc = (q - gg * A * EE) % EE;
+                    if (l.flags[gg * 4 + 3]) dst[q] = l.M[(size_t)gg * EE4 + rc];
+                }
+            }
         }
     }
-    if (p.o.node_obs) {
+    if (p.o.node_obs && !(abl & 2)) {
         // node row (ego i, entity k) = 2 float4: [rel_vel, rel_pos] and [rel_goal, occupied, type]
-        float4* dst = reinterpret_cast<float4*>(p.o.node_obs + (size_t)n * A * E * GMPE_NODE_FEATS);
-        for (int q = tid; q < A * E * 2; q += BLOCK) {
-            const int half = q & 1, row = q >> 1;
-            const int i = row / E, k = row - i * E;
-            const double px = l.ex[i], py = l.ey[i];
-            const double rx = l.ex[k] - px, ry = l.ey[k] - py;
-            float4 v;
+        float4* dst = reinterpret_cast<float4*>(p.o.node_obs + (size_t)n0 * A * E * GMPE_NODE_FEATS);
+        const int per_env = A * E * 2;
+        for (int q = tid; q < Gv * per_env; q += BLOCK) {
+            const int gg = fdiv(q, per_env, p.m_pe), rem = q - gg * per_env;
+            if (!l.flags[gg * 4 + 3]) continue;
+            const int half = rem & 1, row = rem >> 1;
+            const int ei = fdiv(row, E, p.m_E), k = row - ei * E;
+            const int ab = gg * A, eb = gg * E;
+            const double px = l.ex[eb + ei], py = l.ey[eb + ei];
+            const double rx = l.ex[eb + k] - px, ry = l.ey[eb + k] - py;
+            float4 val;
             if (half == 0) {
-                const double evx = l.newf[i] ? l.vnx[i] : l.vox[i], evy = l.newf[i] ? l.vny[i] : l.voy[i];
+                const bool en = l.newf[ab + ei] != 0;
+                const double evx = en ? l.vnx[ab + ei] : l.vox[ab + ei], evy = en ? l.vny[ab + ei] : l.voy[ab + ei];
                 double kvx = 0.0, kvy = 0.0;
-                if (k < A) { const bool post = l.newf[k] && k <= i; kvx = post ? l.vnx[k] : l.vox[k]; kvy = post ? l.vny[k] : l.voy[k]; }
-                v = make_float4((float)(kvx - evx), (float)(kvy - evy), (float)rx, (float)ry);
+                if (k < A) { const bool post = l.newf[ab + k] && k <= ei; kvx = post ? l.vnx[ab + k] : l.vox[ab + k]; kvy = post ? l.vny[ab + k] : l.voy[ab + k]; }
+                val = make_float4((float)(kvx - evx), (float)(kvy - evy), (float)rx, (float)ry);
             } else {
-                if (k < A) v = make_float4((float)(l.ex[A + k] - px), (float)(l.ey[A + k] - py), 0.0f, 0.0f);
-                else v = make_float4((float)rx, (float)ry, 1.0f, k < A + L ? 1.0f : 2.0f);
+                if (k < A) val = make_float4((float)(l.ex[eb + A + k] - px), (float)(l.ey[eb + A + k] - py), 0.0f, 0.0f);
+                else val = make_float4((float)rx, (float)ry, 1.0f, k < A + L ? 1.0f : 2.0f);
             }
-            dst[q] = v;
+            dst[q] = val;
         }
     }
     if (p.o.obs) {
-        float* dst = p.o.obs + (size_t)n * A * D;
-        for (int q = tid; q < A * D; q += BLOCK) dst[q] = l.obs[q];
+        float* dst = p.o.obs + (size_t)n0 * A * D;
+        const int AD = A * D;
+        for (int q = tid; q < Gv * AD; q += BLOCK) { const int gg = fdiv(q, AD, p.m_AD); if (l.flags[gg * 4 + 3]) dst[q] = l.obs[(size_t)gg * AD4 + (q - gg * AD)]; }
     }
-    if (p.o.agent_id) for (int q = tid; q < A; q += BLOCK) p.o.agent_id[(size_t)n * A + q] = q;   // get_id :1554
+    if (p.o.agent_id) for (int q = tid; q < Gv * A; q += BLOCK) { const int gg = q / A; if (l.flags[gg * 4 + 3]) p.o.agent_id[(size_t)n0 * A + q] = q - gg * A; }   // get_id :1554
 }
 
+}  // namespace gmpe
+
+namespace gmpe {
 // ---------------------------------------------------------------- learner-side edge set
 // process_adj (onpolicy/algorithms/utils/gnn_new.py:329-358): mask = (adj < d) & (adj > 0) on fp32
 // (inclusive=1 gives update_graph's `<=`, …_july.py:1660), edges in (batch,row,col) order, node ids
@@ -718,6 +836,8 @@ struct gmpe_handle {
     double t_total_ms = 0;
     int64_t t_launches = 0;
     int block = 0;
+    int G = 1;                       // envs per workgroup
+    int ablate = 0;
     int32_t* edge_ws = nullptr;      // [2*cap_graphs] counts | offsets
     size_t edge_ws_graphs = 0;
 };
@@ -814,12 +934,35 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     AL(s.conformance, NA, 0) AL(s.goal_min_time, NA, 0) AL(s.delta_spacing, N, 0) AL(s.error_flags, N, 0)
 #undef AL
     s.tape = nullptr; s.tape_len = 0;
-    // workgroup size: one wave for small graphs, up to 4 waves when E*E output rows dominate
+    // Tile shape. G envs per workgroup so that the sequential-semantics passes fill wave 0 (G*A <= 64)
+    // while the per-tile LDS stays small enough for several workgroups per CU; BLOCK threads share the
+    // distance pass and the stores. GMPE_G / GMPE_BLOCK override the heuristic (tuning, tests).
+    const char* env_g = getenv("GMPE_G");
     const char* env_block = getenv("GMPE_BLOCK");
-    h->block = env_block ? atoi(env_block) : (E <= 24 ? 64 : (E <= 48 ? 128 : 256));
+    int G = env_g ? atoi(env_g) : 64 / h->A;
+    if (G < 1) G = 1;
+    if (G > 64 / h->A) G = 64 / h->A;
+    if (G > (int)N) G = (int)N;
+    while (G > 1 && lds_bytes(G, h->A, E, h->D) > 48 * 1024) --G;
+    {   // exact magic division (fdiv) needs q*d < 2^32 for every (range, divisor) pair the kernel uses
+        const uint64_t AE = (uint64_t)h->A * E, EE = (uint64_t)E * E;
+        const uint64_t worst = (uint64_t)G * (2 * AE > EE ? 2 * AE : EE) * (2 * AE > EE ? 2 * AE : EE);
+        if (worst >= (1ull << 32) || (uint64_t)G * h->A * EE * h->A * EE >= (1ull << 40)) { gmpe_destroy(h); return fail(GMPE_ERR_UNSUPPORTED, "tile too large for the index arithmetic"); }
+    }
+    h->G = G;
+    h->ablate = getenv("GMPE_ABLATE") ? atoi(getenv("GMPE_ABLATE")) : 0;
+    const size_t stream_f4 = (size_t)G * h->A * ((size_t)E * E / 4 + 2 * (size_t)E);
+    h->block = env_block ? atoi(env_block) : (stream_f4 <= 2048 ? 64 : (stream_f4 <= 8192 ? 128 : 256));
     if (h->block != 64 && h->block != 128 && h->block != 256) h->block = 256;
-    const size_t lds = lds_bytes(h->A, E, h->D);
-    if (lds > 160 * 1024) { gmpe_destroy(h); return fail(GMPE_ERR_UNSUPPORTED, "per-env LDS tile exceeds 160 KiB"); }
+    const size_t lds = lds_bytes(h->G, h->A, E, h->D);
+    if (lds > 160 * 1024) { gmpe_destroy(h); return fail(GMPE_ERR_UNSUPPORTED, "per-tile LDS exceeds 160 KiB"); }
+    if (lds > 48 * 1024) {                                   // opt in to >64 KiB dynamic LDS (gfx950: 160 KiB per CU)
+        hipError_t e = hipSuccess;
+        if (h->block == 64) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else if (h->block == 128) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { gmpe_destroy(h); return fail(GMPE_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
+    }
     *out = h;
     return GMPE_OK;
 }
@@ -870,11 +1013,15 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
     p.c = h->c; p.s = h->s;
     if (out) p.o = *out;
     p.act = act; p.onehot = onehot; p.mask = mask; p.mode = mode;
-    p.A = h->A; p.L = h->L; p.O = h->O; p.E = h->E; p.D = h->D;
+    p.A = h->A; p.L = h->L; p.O = h->O; p.E = h->E; p.D = h->D; p.G = h->G;
+    p.ablate = h->ablate;
+    p.m_E = magic_of(p.E); p.m_AE = magic_of(p.A * p.E); p.m_EE = magic_of(p.E * p.E); p.m_nq = magic_of(p.E * p.E / 4);
+    p.m_2E = magic_of(2 * p.E); p.m_pe = magic_of(p.A * p.E * 2); p.m_AD = magic_of(p.A * p.D); p.m_A = magic_of(p.A);
+    p.m_L = magic_of(p.L); p.m_O = magic_of(p.O);
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t lds = lds_bytes(h->A, h->E, h->D);
-    const dim3 grid(h->c.num_envs);
+    const size_t lds = lds_bytes(h->G, h->A, h->E, h->D);
+    const dim3 grid((h->c.num_envs + h->G - 1) / h->G);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing) {
         if (h->ev_used + 2 > h->ev.size()) {
