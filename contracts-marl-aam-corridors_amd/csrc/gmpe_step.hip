@@ -42,6 +42,7 @@ struct KParams {
     int ablate;               // debug: timing-only builds of the kernel skip parts (GMPE_ABLATE)
     // magic multipliers for exact unsigned division by run-time constants (q < 2^22): floor(q/d) = umulhi(q, m)
     uint32_t m_E, m_AE, m_EE, m_nq, m_2E, m_pe, m_AD, m_A, m_L, m_O;
+    unsigned long long* stamps;   // diagnostic build only (-DGMPE_STAMPS): [grid][16] s_memtime per phase
 };
 __host__ __device__ inline uint32_t magic_of(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(0x100000000ull / d) + 1u; }
 __device__ __forceinline__ int fdiv(int q, int d, uint32_t m) { return d <= 1 ? q : (int)__umulhi((uint32_t)q, m); }
@@ -288,9 +289,18 @@ __device__ __forceinline__ void distance_rows(const KParams& p, const Lds& l, in
     }
 }
 
+#ifndef GMPE_MIN_WAVES
+#define GMPE_MIN_WAVES 1
+#endif
+#ifdef GMPE_STAMPS
+#define STAMP(k) do { if (tid == 0 && p.stamps) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------- the fused kernel
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
+__global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int A = p.A, L = p.L, O = p.O, E = p.E, D = p.D, G = p.G, N = p.c.num_envs;
@@ -319,6 +329,7 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
     int err = 0;
     int64_t ctr0 = 0;
 
+    STAMP(0);
     // ---- 0. load state
     for (int q = tid; q < Gv * GMPE_TUBE_STRIDE; q += BLOCK) l.tube[q] = p.s.tube[(size_t)n0 * GMPE_TUBE_STRIDE + q];
     for (int q = tid; q < Gv * L; q += BLOCK) {
@@ -350,12 +361,14 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
         }
     }
     __syncthreads();
+    STAMP(1);
 
     int ph1 = 0;
     if (step) {
         cur_step += 1;
         // ---- 1. action decode + dynamics
         if (!kinematic(c)) { distance_rows<BLOCK>(p, l, Gv, tid, false); __syncthreads(); }   // pre-move distances for the contact forces
+        STAMP(2);
         double nx = 0, ny = 0, nv2 = 0, nv3 = 0;
         if (ag) {
             int idx;
@@ -423,11 +436,13 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
                 p_dist += sqrt(ax * ax + ay * ay); tim += c.dt;
             }
         }
+        STAMP(3);
         __syncthreads();                                                // all lanes have read the old positions
         if (ag) { v.ex[i] = nx; v.ey[i] = ny; v.s2[i] = nv2; v.s3[i] = nv3; }
         __syncthreads();
         distance_rows<BLOCK>(p, l, Gv, tid, false);                    // post-move rows: obs, reward, info, adj all read these
         __syncthreads();
+        STAMP(4);
 
         // ---- 2. phase FSM + who newly reaches the goal (depends only on own data: SURVEY §8a)
         int cp = 0, prevA = prev_phase;
@@ -465,6 +480,7 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
             }
         }
         __syncthreads();
+        STAMP(5);
 
         // ---- 3. obs, reward, done (ego i sees agent k done iff s_old[k] || (new[k] && k < i))
         double rew = 0; bool done = false;
@@ -556,6 +572,7 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
             if (ag && i == 0) v.flags[0] = all_done;
         }
         __syncthreads();
+        STAMP(6);
 
         // ---- 4. info (sequential view: agents j<=i already updated, j>i not yet), outputs, write-back
         if (ag) {
@@ -614,6 +631,7 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
             }
         }
         __syncthreads();
+        STAMP(7);
     }
 
     // ---- 5. reset (explicit, or the worker's auto-reset when every agent of the env is done)
@@ -655,6 +673,7 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
     }
     if (ag && err) atomicOr(&p.s.error_flags[n], err);
     __syncthreads();
+    STAMP(8);
 
     const int abl = p.ablate;
     // ---- 6. masked distance matrix (calculate_distances core.py:600-624 + mask …_july.py:1627-1648), fp32 in LDS
@@ -682,6 +701,7 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
         l.M[(size_t)gg * EE4 + rc] = (float)d;
     }
     __syncthreads();
+    STAMP(9);
 
     // ---- 7. stream the observations out (16-byte stores wherever the row length allows)
     if (p.o.adj && !(abl & 1)) {
@@ -715,6 +735,7 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
             }
         }
     }
+    STAMP(10);
     if (p.o.node_obs && !(abl & 2)) {
         // node row (ego i, entity k) = 2 float4: [rel_vel, rel_pos] and [rel_goal, occupied, type]
         float4* dst = reinterpret_cast<float4*>(p.o.node_obs + (size_t)n0 * A * E * GMPE_NODE_FEATS);
@@ -741,12 +762,14 @@ __global__ __launch_bounds__(BLOCK) void k_env(const KParams p) {
             dst[q] = val;
         }
     }
+    STAMP(11);
     if (p.o.obs) {
         float* dst = p.o.obs + (size_t)n0 * A * D;
         const int AD = A * D;
         for (int q = tid; q < Gv * AD; q += BLOCK) { const int gg = fdiv(q, AD, p.m_AD); if (l.flags[gg * 4 + 3]) dst[q] = l.obs[(size_t)gg * AD4 + (q - gg * AD)]; }
     }
     if (p.o.agent_id) for (int q = tid; q < Gv * A; q += BLOCK) { const int gg = q / A; if (l.flags[gg * 4 + 3]) p.o.agent_id[(size_t)n0 * A + q] = q - gg * A; }   // get_id :1554
+    STAMP(12);
 }
 
 }  // namespace gmpe
@@ -838,6 +861,7 @@ struct gmpe_handle {
     int block = 0;
     int G = 1;                       // envs per workgroup
     int ablate = 0;
+    unsigned long long* stamps = nullptr;
     int32_t* edge_ws = nullptr;      // [2*cap_graphs] counts | offsets
     size_t edge_ws_graphs = 0;
 };
@@ -963,9 +987,27 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
         else e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { gmpe_destroy(h); return fail(GMPE_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
     }
+#ifdef GMPE_STAMPS
+    {
+        const size_t grid = (N + G - 1) / G;
+        void* q = nullptr;
+        if (hipMalloc(&q, grid * 16 * 8) == hipSuccess) { (void)hipMemset(q, 0, grid * 16 * 8); h->allocs.push_back(q); h->stamps = static_cast<unsigned long long*>(q); }
+    }
+#endif
     *out = h;
     return GMPE_OK;
 }
+
+#ifdef GMPE_STAMPS
+// diagnostic build only: copy the per-workgroup phase stamps of the LAST launch to the host
+int gmpe_debug_stamps(gmpe_handle* h, unsigned long long* host_dst, int64_t max_blocks) {
+    const int64_t grid = (h->c.num_envs + h->G - 1) / h->G;
+    const int64_t nb = grid < max_blocks ? grid : max_blocks;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(host_dst, h->stamps, (size_t)nb * 16 * 8, hipMemcpyDeviceToHost));
+    return (int)nb;
+}
+#endif
 
 int gmpe_destroy(gmpe_handle* h) {
     if (!h) return GMPE_OK;
@@ -1015,6 +1057,7 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
     p.act = act; p.onehot = onehot; p.mask = mask; p.mode = mode;
     p.A = h->A; p.L = h->L; p.O = h->O; p.E = h->E; p.D = h->D; p.G = h->G;
     p.ablate = h->ablate;
+    p.stamps = h->stamps;
     p.m_E = magic_of(p.E); p.m_AE = magic_of(p.A * p.E); p.m_EE = magic_of(p.E * p.E); p.m_nq = magic_of(p.E * p.E / 4);
     p.m_2E = magic_of(2 * p.E); p.m_pe = magic_of(p.A * p.E * 2); p.m_AD = magic_of(p.A * p.D); p.m_A = magic_of(p.A);
     p.m_L = magic_of(p.L); p.m_O = magic_of(p.O);

@@ -1,0 +1,184 @@
+"""BatchedGraphMPEVecEnv — same surface as GraphSubprocVecEnv, backed by the HIP engine.
+
+Mirrors onpolicy/envs/env_wrappers.py:959-1037 (class GraphSubprocVecEnv) and its base ShareVecEnv
+(:28-141): `num_envs`, the eight space lists, `reset(num_current_episode)`,
+`step_async/step_wait/step(actions, num_current_episode)`, `close()`, `render()`.
+Where the reference forks N processes that each run MultiAgentGraphEnv.step
+(multiagent/environment.py:1021-1063) and ship pickled fp64 arrays through pipes, this class makes
+ONE kernel launch per step for all N envs and hands the runner NumPy views in the dtypes its
+buffer stores (float32 / int32 / bool; onpolicy/utils/graph_buffer.py:84-114).
+"""
+import numpy as np
+import torch
+
+from .config import INFO_KEYS, NODE_FEATS, config_from_args
+from .engine import GmpeEngine
+from .spaces import Box, Discrete
+
+
+class LazyInfos(object):
+    """Sequence of N per-env info lists, materialised from the device counters only when read.
+
+    The runner touches infos only every `log_interval` episodes (graph_mpe_runner.py:166-189,
+    base_runner.py:194-290: `for info in infos: info[agent_id][key]`); building 4096x10 dicts of 17
+    keys every step would dominate the host, so the dicts are created on first access.
+    """
+
+    def __init__(self, info_dev, n_envs, n_agents, include_min_time=True):
+        self._dev = info_dev
+        self._host = None
+        self._n, self._a = n_envs, n_agents
+        self._keys = INFO_KEYS if include_min_time else INFO_KEYS[:-1]
+
+    def _fetch(self):
+        if self._host is None:
+            self._host = self._dev.detach().cpu().numpy().astype(np.float64)
+            self._dev = None
+        return self._host
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, e):
+        if isinstance(e, slice):
+            return [self[i] for i in range(*e.indices(self._n))]
+        if e < 0:
+            e += self._n
+        if not 0 <= e < self._n:
+            raise IndexError(e)
+        h = self._fetch()
+        return [dict(zip(self._keys, h[e, a, :len(self._keys)].tolist())) for a in range(self._a)]
+
+    def __iter__(self):
+        for e in range(self._n):
+            yield self[e]
+
+    def as_array(self):
+        """[N, A, 17] float64 in config.INFO_KEYS order (no dict construction)."""
+        return self._fetch()
+
+
+class BatchedGraphMPEVecEnv(object):
+    """Drop-in for GraphSubprocVecEnv([get_env_fn(i) for i in range(n_rollout_threads)])."""
+    closed = False
+    viewer = None
+    metadata = {"render.modes": ["human", "rgb_array"]}
+
+    def __init__(self, all_args, num_envs=None, device=0, env_id_base=0, adj_broadcast_view=True):
+        self.cfg = config_from_args(all_args, num_envs=num_envs, env_id_base=env_id_base)
+        # The reference's per-agent adj arrays alias ONE E x E matrix per env, so the
+        # engine writes that matrix once and the [N,A,E,E] result is a zero-copy broadcast view.
+        self._compact = bool(adj_broadcast_view)
+        self.engine = GmpeEngine(self.cfg, device=device, adj_compact=self._compact, with_info=True)
+        c = self.cfg
+        self.num_envs = c.num_envs
+        self.num_agents = self.n = c.num_agents
+        A, E, D = c.num_agents, c.num_entities, c.obs_dim
+        f32 = np.float32
+        # spaces: multiagent/environment.py:152-208 (obs/share_obs/action) and :986-1018 (graph)
+        self.observation_space = [Box(-np.inf, np.inf, (D,), f32) for _ in range(A)]
+        self.share_observation_space = [Box(-np.inf, np.inf, (A * D,), f32) for _ in range(A)]
+        self.action_space = [Discrete(c.n_actions) for _ in range(A)]
+        self.node_observation_space = [Box(-np.inf, np.inf, (E, NODE_FEATS), f32) for _ in range(A)]
+        self.adj_observation_space = [Box(-np.inf, np.inf, (E, E), f32) for _ in range(A)]
+        self.edge_observation_space = [Box(-np.inf, np.inf, (1,), f32) for _ in range(A)]
+        self.agent_id_observation_space = [Box(-np.inf, np.inf, (1,), f32) for _ in range(A)]
+        self.share_agent_id_observation_space = [Box(-np.inf, np.inf, (A * 1,), f32) for _ in range(A)]
+        self.waiting = False
+        self._pending = None
+
+    # ------------------------------------------------------------------ helpers
+    def _adj_np(self, adj):
+        a = adj.detach().cpu().numpy()
+        if self._compact:
+            N, E = a.shape[0], a.shape[-1]
+            a = np.broadcast_to(a[:, None], (N, self.num_agents, E, E))
+        return a
+
+    def _obs_tuple(self, o):
+        return (o.obs.detach().cpu().numpy(), o.agent_id.detach().cpu().numpy(),
+                o.node_obs.detach().cpu().numpy(), self._adj_np(o.adj))
+
+    # ------------------------------------------------------------------ GraphSubprocVecEnv surface
+    def reset(self, num_current_episode=0):
+        """-> (obs [N,A,D], agent_id [N,A,1], node_obs [N,A,E,F], adj [N,A,E,E])  (env_wrappers.py:1006-1013)"""
+        o = self.engine.reset()
+        return self._obs_tuple(o)
+
+    def step_async(self, actions, num_current_episode=None):
+        """actions: [N, A, n_actions] one-hot (graph_mpe_runner.py:375-377), or [N, A] integer indices."""
+        if self.waiting:
+            raise RuntimeError("step_async called while a step is pending")
+        if torch.is_tensor(actions):
+            a = actions
+        else:
+            a = np.asarray(actions)
+        if a.ndim == 3:
+            if a.shape != (self.num_envs, self.num_agents, self.cfg.n_actions):
+                raise ValueError("actions must be [N=%d, A=%d, %d]" % (self.num_envs, self.num_agents, self.cfg.n_actions))
+            t = torch.as_tensor(a, dtype=torch.float32)
+            self._pending = self.engine.step_onehot(t.to(self.engine.device, non_blocking=True))
+        elif a.ndim == 2:
+            if tuple(a.shape) != (self.num_envs, self.num_agents):
+                raise ValueError("actions must be [N=%d, A=%d]" % (self.num_envs, self.num_agents))
+            t = torch.as_tensor(a).to(dtype=torch.int32)
+            self._pending = self.engine.step(t.to(self.engine.device, non_blocking=True))
+        else:
+            raise ValueError("actions must be a one-hot [N,A,n_act] or an index [N,A] array")
+        self.waiting = True
+
+    def step_wait(self):
+        """-> 7-tuple (obs, agent_id, node_obs, adj, rewards [N,A], dones [N,A] bool, infos)
+        (env_wrappers.py:996-1004). Envs whose agents were all done carry POST-reset observations with
+        the terminal reward/done (graphworker, env_wrappers.py:865-873)."""
+        if not self.waiting:
+            raise RuntimeError("step_wait without step_async")
+        o = self._pending
+        self._pending, self.waiting = None, False
+        obs, ids, node, adj = self._obs_tuple(o)                 # .cpu() synchronises the stream
+        rew = o.reward.detach().cpu().numpy()
+        done = o.done.detach().cpu().numpy().astype(bool)
+        infos = LazyInfos(o.info.clone(), self.num_envs, self.num_agents, include_min_time=self.cfg.max_speed > 0)
+        return obs, ids, node, adj, rew, done, infos
+
+    def step(self, actions, num_current_episode=None):
+        self.step_async(actions, num_current_episode)
+        return self.step_wait()
+
+    def reset_task(self):
+        raise NotImplementedError("reset_task is not part of the GraphMPE path")
+
+    def render(self, mode="rgb_array"):
+        raise NotImplementedError("rendering (pyglet viewer) is out of scope of the step engine")
+
+    def close(self):
+        if self.closed:
+            return
+        self.engine.close()
+        self.closed = True
+
+    @property
+    def unwrapped(self):
+        return self
+
+    # ------------------------------------------------------------------ extras (not in the reference)
+    def step_device(self, action_idx):
+        """Zero-copy variant: int32 device tensor in, device tensors out (engine.StepOutputs)."""
+        return self.engine.step(action_idx)
+
+    def seed(self, seed=None):
+        raise NotImplementedError("seeds are part of the config (args.seed): per-env streams are keyed by "
+                                  "(seed, env id), the counterpart of env.seed(seed + rank*1000) in train_mpe.py:31")
+
+
+def make_train_env(all_args, device=0):
+    """Counterpart of onpolicy/scripts/train_mpe.py:21-43 for env_name == 'GraphMPE'."""
+    if getattr(all_args, "env_name", "GraphMPE") != "GraphMPE":
+        raise NotImplementedError("only the GraphMPE route is built")
+    return BatchedGraphMPEVecEnv(all_args, num_envs=all_args.n_rollout_threads, device=device)
+
+
+def GraphMPEEnv(args, device=0):
+    """multiagent/MPE_env.py:56-84 builds ONE env; here that is a batch of one."""
+    assert "graph" in args.scenario_name, "Only use graph env for graph scenarios"
+    return BatchedGraphMPEVecEnv(args, num_envs=1, device=device)

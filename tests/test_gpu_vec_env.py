@@ -1,0 +1,99 @@
+"""The drop-in boundary driven the way the rmappo runner drives GraphSubprocVecEnv
+(onpolicy/runner/shared/graph_mpe_runner.py:40-207, 213-238, 343-382)."""
+import argparse
+
+import numpy as np
+import pytest
+
+import gmpe
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(**over):
+    d = dict(env_name="GraphMPE", scenario_name="nav_metered_one_goal_graph_rotate_tube_july", dynamics_type="air_taxi",
+             world_size=4, num_agents=4, num_landmarks=4, num_scripted_agents=0, num_obstacles=0, num_walls=0,
+             collaborative=False, max_speed=2, collision_rew=5, formation_rew=1, goal_rew=5, use_dones=False,
+             episode_length=6, num_env_steps=10000, n_rollout_threads=32, render_episodes=None, fair_wt=1, fair_rew=1,
+             formation_type="point", total_actions=5, zeroshift=5, graph_feat_type="relative", discrete_action=True,
+             use_safety_filter=False, seed=11)
+    d.update(over)
+    return argparse.Namespace(**d)
+
+
+def test_runner_loop_contract_and_oracle_parity():
+    from gmpe.vec_env import make_train_env
+    from onpolicy_shapes import get_shape_from_obs_space, get_shape_from_act_space
+    a = _args()
+    envs = make_train_env(a)
+    N, A, E = a.n_rollout_threads, a.num_agents, 2 * a.num_agents
+    assert envs.num_envs == N
+    # base_runner.py:81-119 reads these eight lists
+    assert get_shape_from_obs_space(envs.observation_space[0]) == (19,)
+    assert get_shape_from_obs_space(envs.share_observation_space[0]) == (A * 19,)
+    assert get_shape_from_obs_space(envs.node_observation_space[0]) == (E, 8)
+    assert get_shape_from_obs_space(envs.adj_observation_space[0]) == (E, E)
+    assert get_shape_from_obs_space(envs.edge_observation_space[0]) == (1,)
+    assert get_shape_from_obs_space(envs.agent_id_observation_space[0]) == (1,)
+    assert get_shape_from_obs_space(envs.share_agent_id_observation_space[0]) == (A,)
+    assert get_shape_from_act_space(envs.action_space[0]) == 1 and envs.action_space[0].n == 25
+
+    orc = ol.Oracle(envs.cfg)
+    obs, agent_id, node_obs, adj = envs.reset()
+    oo = orc.reset()
+    assert obs.shape == (N, A, 19) and agent_id.shape == (N, A, 1) and node_obs.shape == (N, A, E, 8) and adj.shape == (N, A, E, E)
+    assert obs.dtype == np.float32 and adj.dtype == np.float32 and agent_id.dtype == np.int32
+    np.testing.assert_allclose(obs, oo[0], atol=1e-5)
+    rng = np.random.RandomState(0)
+    resets = 0
+    for step in range(15):
+        actions = rng.randint(0, 25, (N, A))
+        actions_env = np.squeeze(np.eye(25)[actions], 0) if N == 0 else np.eye(25)[actions]      # runner :375-377
+        obs, agent_id, node_obs, adj, rewards, dones, infos = envs.step(actions_env, step)
+        oo = orc.step(actions)
+        assert rewards.shape == (N, A) and dones.shape == (N, A) and dones.dtype == bool
+        rewards[:, :, np.newaxis]                                                               # runner :94
+        masks = np.ones((N, A, 1), dtype=np.float32); masks[dones == True] = 0                  # runner :85-90  # noqa: E712
+        np.testing.assert_allclose(obs, oo[0], atol=1e-5)
+        np.testing.assert_allclose(node_obs, oo[2], atol=1e-5)
+        np.testing.assert_allclose(adj, np.broadcast_to(oo[3][:, None], adj.shape), atol=1e-5)
+        np.testing.assert_allclose(rewards, oo[4], atol=1e-5)
+        np.testing.assert_array_equal(dones, oo[5])
+        resets += int(oo[7].sum())
+        if step % 5 == 4:                                                                       # log_interval path
+            assert len(infos) == N and len(infos[0]) == A
+            for k in ("Distance_mean", "Dist_to_goal", "individual_reward", "Num_agent_collisions", "Min_time_to_goal"):
+                assert k in infos[3][1]
+            np.testing.assert_allclose(infos.as_array(), oo[6], rtol=2e-6, atol=2e-5)
+    assert resets >= 2 * N          # episode_length 6 -> auto-resets happened and were matched
+    envs.close()
+
+
+def test_index_actions_and_errors():
+    from gmpe.vec_env import BatchedGraphMPEVecEnv
+    envs = BatchedGraphMPEVecEnv(_args(n_rollout_threads=4), num_envs=4)
+    envs.reset()
+    out = envs.step(np.zeros((4, 4), dtype=np.int64))
+    assert len(out) == 7
+    with pytest.raises(ValueError):
+        envs.step(np.zeros((3, 4), dtype=np.int64))
+    with pytest.raises(RuntimeError):
+        envs.step_wait()
+    with pytest.raises(NotImplementedError):
+        envs.render()
+    envs.close(); envs.close()
+
+
+def test_navigation_graph_vec_env():
+    from gmpe.vec_env import make_train_env
+    a = _args(scenario_name="navigation_graph", dynamics_type="double_integrator", num_agents=5, num_landmarks=5,
+              num_obstacles=2, num_walls=4, world_size=3, n_rollout_threads=16)
+    envs = make_train_env(a)
+    assert envs.action_space[0].n == 5 and envs.observation_space[0].shape == (13,)
+    obs, ids, node, adj = envs.reset()
+    assert node.shape == (16, 5, 12, 8) and adj.shape == (16, 5, 12, 12)
+    for t in range(8):
+        o = envs.step(np.eye(5)[np.random.RandomState(t).randint(0, 5, (16, 5))])
+        assert np.isfinite(o[0]).all() and o[4].shape == (16, 5)
+    envs.close()
