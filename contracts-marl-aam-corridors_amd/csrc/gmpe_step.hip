@@ -41,7 +41,7 @@ struct KParams {
     int G;                    // envs per workgroup (G*A <= 64)
     int ablate;               // debug: timing-only builds of the kernel skip parts (GMPE_ABLATE)
     // magic multipliers for exact unsigned division by run-time constants (q < 2^22): floor(q/d) = umulhi(q, m)
-    uint32_t m_E, m_AE, m_EE, m_nq, m_2E, m_pe, m_AD, m_A, m_L, m_O;
+    uint32_t m_E, m_AE, m_EE, m_nq, m_2E, m_pe, m_AD, m_A, m_L, m_O, m_S, m_SS, m_C, m_AC, m_AEE;
     unsigned long long* stamps;   // diagnostic build only (-DGMPE_STAMPS): [grid][16] s_memtime per phase
 };
 __host__ __device__ inline uint32_t magic_of(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(0x100000000ull / d) + 1u; }
@@ -62,7 +62,8 @@ struct Lds {
     double *Dm;                       // [G][A][E] fp64 agent->entity distances (rows of cached_dist_mag)
     int *s_old, *newf, *gt;           // [G][A]  status before, newly-reached flag, goal_tracker (final)
     int *dtg_o, *dtg_n, *trq_o, *trq_n, *sv_o, *sv_n;   // [G][A] info counters old/new
-    int *flags;                       // [G][4]  0: reset this env, 1: heading draws this step, 3: env active
+    int *flags;                       // [G][4]  0: reset this env, 1: heading draws this step, 2: env has masked nodes, 3: env active
+    int *moff;                        // [G][E]  adjacency mask per node (done agent / reached landmark)
     float *obs;                       // [G][A*D] staging
     float *M;                         // [G][E*E] masked distance matrix, fp32
 };
@@ -70,7 +71,7 @@ __host__ __device__ inline size_t lds_bytes(int G, int A, int E, int D) {
     const size_t EE4 = ((size_t)E * E + 3) / 4 * 4, AD4 = ((size_t)A * D + 3) / 4 * 4;
     size_t d = (size_t)G * (2 * E + 10 * A + 12 + (size_t)A * E);   // doubles
     size_t f = (size_t)G * (EE4 + AD4);                             // floats
-    size_t i = (size_t)G * (9 * A + 4);                             // ints
+    size_t i = (size_t)G * (9 * A + 4 + E);                         // ints
     return d * 8 + 16 + f * 4 + ((i * 4 + 15) / 16) * 16 + 32;
 }
 __device__ inline Lds carve(char* base, int G, int A, int E, int D) {
@@ -89,7 +90,7 @@ __device__ inline Lds carve(char* base, int G, int A, int E, int D) {
     int* i = reinterpret_cast<int*>(f);
     l.s_old = i; i += G * A; l.newf = i; i += G * A; l.gt = i; i += G * A;
     l.dtg_o = i; i += G * A; l.dtg_n = i; i += G * A; l.trq_o = i; i += G * A; l.trq_n = i; i += G * A;
-    l.sv_o = i; i += G * A; l.sv_n = i; i += G * A; l.flags = i;
+    l.sv_o = i; i += G * A; l.sv_n = i; i += G * A; l.flags = i; i += G * 4; l.moff = i;
     return l;
 }
 // view of env g inside the workgroup tile
@@ -103,7 +104,7 @@ __device__ inline Lds env_view(const Lds& l, int g, int A, int E, int D) {
     v.Dm = l.Dm + (size_t)g * A * E;
     v.s_old = l.s_old + g * A; v.newf = l.newf + g * A; v.gt = l.gt + g * A;
     v.dtg_o = l.dtg_o + g * A; v.dtg_n = l.dtg_n + g * A; v.trq_o = l.trq_o + g * A; v.trq_n = l.trq_n + g * A;
-    v.sv_o = l.sv_o + g * A; v.sv_n = l.sv_n + g * A; v.flags = l.flags + g * 4;
+    v.sv_o = l.sv_o + g * A; v.sv_n = l.sv_n + g * A; v.flags = l.flags + g * 4; v.moff = l.moff + g * E;
     v.obs = l.obs + g * AD4; v.M = l.M + g * EE4;
     return v;
 }
@@ -271,21 +272,35 @@ __device__ void reset_world_serial(const KParams& p, const Lds& l, int n, int64_
 }
 
 
-// fp64 agent->entity distance rows for every env of the tile (World.calculate_distances,
-// core.py:600-624: delta taken as pos[min]-pos[max], so the matrix is exactly symmetric).
+// Post-move distance pass for every env of the tile (World.calculate_distances, core.py:600-624:
+// delta taken as pos[min]-pos[max], so the matrix is exactly symmetric). Writes the fp64 agent rows
+// Dm[g][r][c] AND the unmasked fp32 matrix M (agent rows + their mirrored columns); the static
+// (landmark/obstacle) x (landmark/obstacle) block is filled by static_block().
 template <int BLOCK>
-__device__ __forceinline__ void distance_rows(const KParams& p, const Lds& l, int G, int tid, bool only_reset) {
-    const int A = p.A, E = p.E, AE = A * E;
+__device__ __forceinline__ void distance_pass(const KParams& p, const Lds& l, int G, int tid, bool only_reset) {
+    const int A = p.A, E = p.E, AE = A * E, EE4 = (E * E + 3) / 4 * 4;
     for (int q = tid; q < G * AE; q += BLOCK) {
         const int g = fdiv(q, AE, p.m_AE), rc = q - g * AE, r = fdiv(rc, E, p.m_E), cc = rc - r * E;
         if (only_reset && !l.flags[g * 4 + 0]) continue;
-        double d = 0.0;
-        if (r != cc) {
-            const int a = r < cc ? r : cc, b = r < cc ? cc : r;
-            const double dx = l.ex[g * E + a] - l.ex[g * E + b], dy = l.ey[g * E + a] - l.ey[g * E + b];
-            d = sqrt(dx * dx + dy * dy);
-        }
+        const int a = r < cc ? r : cc, b = r < cc ? cc : r;
+        const double dx = l.ex[g * E + a] - l.ex[g * E + b], dy = l.ey[g * E + a] - l.ey[g * E + b];
+        const double d = r != cc ? sqrt(dx * dx + dy * dy) : 0.0;
         l.Dm[q] = d;
+        float* Mg = l.M + (size_t)g * EE4;
+        Mg[rc] = (float)d;
+        if (cc >= A) Mg[cc * E + r] = (float)d;
+    }
+}
+template <int BLOCK>
+__device__ __forceinline__ void static_block(const KParams& p, const Lds& l, int G, int tid, bool only_reset) {
+    const int A = p.A, E = p.E, S = p.L + p.O, SS = S * S, EE4 = (E * E + 3) / 4 * 4;
+    for (int q = tid; q < G * SS; q += BLOCK) {
+        const int g = fdiv(q, SS, p.m_SS), rc = q - g * SS, r3 = fdiv(rc, S, p.m_S), c3 = rc - r3 * S;
+        if (only_reset && !l.flags[g * 4 + 0]) continue;
+        const int r = A + r3, cc = A + c3;
+        const int a = r < cc ? r : cc, b = r < cc ? cc : r;
+        const double dx = l.ex[g * E + a] - l.ex[g * E + b], dy = l.ey[g * E + a] - l.ey[g * E + b];
+        l.M[(size_t)g * EE4 + r * E + cc] = r != cc ? (float)sqrt(dx * dx + dy * dy) : 0.0f;
     }
 }
 
@@ -310,6 +325,9 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
     const int Gv = min(G, N - n0);                                      // envs actually present in this tile
     const bool july = c.scenario == GMPE_SCENARIO_TUBE_JULY;
     const bool step = p.mode == MODE_STEP;
+    const bool kin = kinematic(c);
+    const int EE = E * E, EE4 = (EE + 3) / 4 * 4, AD4 = (A * D + 3) / 4 * 4;
+    const double INF = __builtin_huge_val();
 
     // agent lane mapping: lane tid of wave 0 = (env g, agent i)
     const int g = fdiv(tid, A, p.m_A), i = tid - g * A;
@@ -324,22 +342,23 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
     int prev_phase = 0, phase_reached = 0, cooldown = 0;
     double p_dist = 0, tim = 0;
     int trq = -1, dtg = -1, dleft = -1, greached = -1, nac = 0, noc = 0, sv = 0, sic = 0, conf = 0;
-    double gmt = 0;
-    int cur_step = 0;
+    double gmt = 0, dsp0 = 0;
+    int cur_step = 0, act_idx = 0;
     int err = 0;
     int64_t ctr0 = 0;
 
     STAMP(0);
-    // ---- 0. load state
+    // ---- 0. load state (every global read of the step happens here, in one batch)
     for (int q = tid; q < Gv * GMPE_TUBE_STRIDE; q += BLOCK) l.tube[q] = p.s.tube[(size_t)n0 * GMPE_TUBE_STRIDE + q];
     for (int q = tid; q < Gv * L; q += BLOCK) {
-        const int gg = q / L, k = q - gg * L;
+        const int gg = fdiv(q, L, p.m_L), k = q - gg * L;
         l.ex[gg * E + A + k] = p.s.landmarks[((size_t)n0 * L + q) * 2]; l.ey[gg * E + A + k] = p.s.landmarks[((size_t)n0 * L + q) * 2 + 1];
     }
     for (int q = tid; q < Gv * O; q += BLOCK) {
-        const int gg = q / O, k = q - gg * O;
+        const int gg = fdiv(q, O, p.m_O), k = q - gg * O;
         l.ex[gg * E + A + L + k] = p.s.obstacles[((size_t)n0 * O + q) * 2]; l.ey[gg * E + A + L + k] = p.s.obstacles[((size_t)n0 * O + q) * 2 + 1];
     }
+    for (int q = tid; q < G * E; q += BLOCK) l.moff[q] = 0;
     if (tid < G) {
         const int nn = n0 + tid;
         const bool active = nn < N && (step || !p.mask || p.mask[nn]);
@@ -358,6 +377,14 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
             greached = p.s.goal_reached[na]; nac = p.s.n_agent_coll[na]; noc = p.s.n_obst_coll[na];
             sv = p.s.spacing_viol[na]; sic = p.s.steps_in_corr[na]; conf = p.s.conformance[na];
             gmt = p.s.goal_min_time[na];
+            dsp0 = p.s.delta_spacing[n];
+            if (p.act) act_idx = p.act[na];
+            else {                                                      // np.argmax: first maximum
+                const float* oh = p.onehot + na * c.n_actions;
+                float best = oh[0];
+                for (int q = 1; q < c.n_actions; ++q) { const float x = oh[q]; if (x > best) { best = x; act_idx = q; } }
+            }
+            act_idx = act_idx < 0 ? 0 : (act_idx >= c.n_actions ? c.n_actions - 1 : act_idx);
         }
     }
     __syncthreads();
@@ -366,22 +393,36 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
     int ph1 = 0;
     if (step) {
         cur_step += 1;
-        // ---- 1. action decode + dynamics
-        if (!kinematic(c)) { distance_rows<BLOCK>(p, l, Gv, tid, false); __syncthreads(); }   // pre-move distances for the contact forces
+        const int C = A + O;                                            // colliders: agents + obstacles (landmarks collide=False)
+        double* Fx = reinterpret_cast<double*>(l.M);                    // pair forces alias the (not yet built) fp32 matrix
+        double* Fy = Fx + (size_t)G * A * C;
+        if (!kin) {
+            // ---- 1a. contact forces, one PAIR per lane (get_entity_collision_force core.py:872-906): pair (a, k>a)
+            // computed once with delta = pos[a]-pos[k]; side a gets +F, side k gets -F (summed in 1b).
+            const int AC = A * C;
+            for (int q = tid; q < Gv * AC; q += BLOCK) {
+                const int gg = fdiv(q, AC, p.m_AC), rc = q - gg * AC, a = fdiv(rc, C, p.m_C), kk = rc - a * C;
+                double fx = 0.0, fy = 0.0;
+                if (kk > a) {
+                    const int k = kk < A ? kk : L + kk;                 // entity index of collider kk
+                    const double dx = l.ex[gg * E + a] - l.ex[gg * E + k], dy = l.ey[gg * E + a] - l.ey[gg * E + k];
+                    const double dist = sqrt(dx * dx + dy * dy);
+                    if (dist < c.sep_dist + 50.0 * c.contact_margin) {  // else softplus < 1e-21: below one ulp of the sum
+                        const double pen = logaddexp0(-(dist - c.sep_dist) / c.contact_margin) * c.contact_margin;
+                        fx = c.contact_force * dx / dist * pen; fy = c.contact_force * dy / dist * pen;
+                    }
+                }
+                Fx[q] = fx; Fy[q] = fy;
+            }
+            __syncthreads();
+        }
         STAMP(2);
+        // ---- 1b. action decode + dynamics
         double nx = 0, ny = 0, nv2 = 0, nv3 = 0;
         if (ag) {
-            int idx;
-            if (p.act) idx = p.act[na];
-            else {                                                      // np.argmax: first maximum
-                const float* oh = p.onehot + na * c.n_actions;
-                idx = 0; float best = oh[0];
-                for (int q = 1; q < c.n_actions; ++q) if (oh[q] > best) { best = oh[q]; idx = q; }
-            }
-            idx = idx < 0 ? 0 : (idx >= c.n_actions ? c.n_actions - 1 : idx);
-            double u0, u1; decode_action(c, idx, u0, u1);
+            double u0, u1; decode_action(c, act_idx, u0, u1);
             nx = v.ex[i]; ny = v.ey[i]; nv2 = v.s2[i]; nv3 = v.s3[i];
-            if (kinematic(c)) {
+            if (kin) {
                 if (!v.s_old[i]) {                                      // update_agent_state core.py:819-826
                     const double dt = c.dt, th0 = nv2, v0 = nv3;
                     const double th1 = th0 + u0 * dt, v1 = v0 + u1 * dt;
@@ -400,32 +441,30 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
                     p_dist += vv * dt; tim += dt;
                 }
             } else {
-                // force path core.py:766-845, 872-964: accumulate in the reference's order for this agent:
-                // other entities by ascending index (as side b below its own index, side a above), then walls.
-                double Fx = 1.0 * u0, Fy = 1.0 * u1;
-                const double pax = nx, pay = ny;
-                const double* row = v.Dm + (size_t)i * E;
-                const bool ego_done = v.s_old[i] != 0;
-                for (int k = 0; k < E; ++k) {
-                    if (k == i) continue;
-                    if (k >= A && k < A + L) { k = A + L - 1; continue; }   // landmarks: collide=False
-                    const double dist = row[k];
-                    const double z = -(dist - c.sep_dist) / c.contact_margin;
-                    if (z < -50.0) continue;                            // softplus < 1e-21: below one ulp of the sum
-                    if (k < A && ego_done) continue;                    // done side gets no force (899-900)
-                    const bool ego_is_b = k < i;
-                    const double dx = ego_is_b ? v.ex[k] - pax : pax - v.ex[k];
-                    const double dy = ego_is_b ? v.ey[k] - pay : pay - v.ey[k];
-                    const double pen = logaddexp0(z) * c.contact_margin;
-                    const double fx = c.contact_force * dx / dist * pen, fy = c.contact_force * dy / dist * pen;
-                    if (ego_is_b) { Fx = -fx + Fx; Fy = -fy + Fy; } else { Fx = fx + Fx; Fy = fy + Fy; }
+                // force path core.py:766-845: accumulate in the reference's order for this agent — other
+                // entities by ascending index (side b below its own index, side a above), then walls.
+                double sx = 1.0 * u0, sy = 1.0 * u1;
+                const double* fxg = Fx + (size_t)g * A * C; const double* fyg = Fy + (size_t)g * A * C;
+                const bool ego_live = v.s_old[i] == 0;                  // done side gets no agent-agent force (899-900)
+#pragma unroll 4
+                for (int k = 0; k < A; ++k) {
+                    const bool below = k < i;
+                    const int idx = below ? k * C + i : i * C + k;
+                    const double fx = fxg[idx], fy = fyg[idx];
+                    const bool use = ego_live && k != i && (fx != 0.0 || fy != 0.0);
+                    sx = use ? ((below ? -fx : fx) + sx) : sx;
+                    sy = use ? ((below ? -fy : fy) + sy) : sy;
+                }
+                for (int o = 0; o < O; ++o) {                           // immovable obstacles push regardless of status
+                    const double fx = fxg[i * C + A + o], fy = fyg[i * C + A + o];
+                    if (fx != 0.0 || fy != 0.0) { sx = fx + sx; sy = fy + sy; }
                 }
                 for (int w = 0; w < c.num_walls; ++w) {
                     double wx, wy;
-                    if (wall_force(c.walls[w], pax, pay, c.entity_size, c.wall_contact_force, c.wall_contact_margin, wx, wy)) { Fx = Fx + wx; Fy = Fy + wy; }
+                    if (wall_force(c.walls[w], nx, ny, c.entity_size, c.wall_contact_force, c.wall_contact_margin, wx, wy)) { sx = sx + wx; sy = sy + wy; }
                 }
                 double vx = nv2 * (1 - c.damping), vy = nv3 * (1 - c.damping);
-                vx += (Fx / 1.0) * c.dt; vy += (Fy / 1.0) * c.dt;
+                vx += (sx / 1.0) * c.dt; vy += (sy / 1.0) * c.dt;
                 if (c.max_speed > 0) {
                     const double sp = sqrt(vx * vx + vy * vy);
                     if (sp > c.max_speed) { vx = vx / sp * c.max_speed; vy = vy / sp * c.max_speed; }
@@ -435,12 +474,12 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
                 const double ax = vx * c.dt, ay = vy * c.dt;
                 p_dist += sqrt(ax * ax + ay * ay); tim += c.dt;
             }
+            v.ex[i] = nx; v.ey[i] = ny; v.s2[i] = nv2; v.s3[i] = nv3;   // nobody reads positions between 1a and here
         }
-        STAMP(3);
-        __syncthreads();                                                // all lanes have read the old positions
-        if (ag) { v.ex[i] = nx; v.ey[i] = ny; v.s2[i] = nv2; v.s3[i] = nv3; }
         __syncthreads();
-        distance_rows<BLOCK>(p, l, Gv, tid, false);                    // post-move rows: obs, reward, info, adj all read these
+        STAMP(3);
+        distance_pass<BLOCK>(p, l, Gv, tid, false);                    // post-move rows: obs, reward, info, adj all read these
+        static_block<BLOCK>(p, l, Gv, tid, false);
         __syncthreads();
         STAMP(4);
 
@@ -470,13 +509,13 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
             if (ag) {
                 if (v.newf[i]) {
                     const int rank = __popcll(bal & emask & ((1ull << tid) - 1ull));
-                    if (kinematic(c)) { v.n2[i] = 0.0 + (2 * M_PI - 0.0) * draw_at(c, p.s, n, ctr0 + rank, err); v.n3[i] = c.v_min; }
+                    if (kin) { v.n2[i] = 0.0 + (2 * M_PI - 0.0) * draw_at(c, p.s, n, ctr0 + rank, err); v.n3[i] = c.v_min; }
                     else { v.n2[i] = 0.0; v.n3[i] = 0.0; }
                     v.gt[i] = i;
-                } else { v.n2[i] = v.s2[i]; v.n3[i] = v.s3[i]; }
-                double vx, vy; vel_of(c, v.n2[i], v.n3[i], vx, vy);
-                v.vnx[i] = vx; v.vny[i] = vy;
-                if (i == 0) v.flags[1] = kinematic(c) ? __popcll(bal & emask) : 0;   // draws consumed (DI reset_velocity draws none)
+                    double vx, vy; vel_of(c, v.n2[i], v.n3[i], vx, vy);
+                    v.vnx[i] = vx; v.vny[i] = vy;
+                } else { v.n2[i] = v.s2[i]; v.n3[i] = v.s3[i]; v.vnx[i] = v.vox[i]; v.vny[i] = v.voy[i]; }
+                if (i == 0) v.flags[1] = kin ? __popcll(bal & emask) : 0;   // draws consumed (DI reset_velocity draws none)
             }
         }
         __syncthreads();
@@ -488,15 +527,22 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
             const double px = v.ex[i], py = v.ey[i];
             const double* row = v.Dm + (size_t)i * E;
             write_obs(p, v, i, v.vox[i], v.voy[i], ph1);
-            // collision block (…_july.py:1117-1124)
-            if (!v.s_old[i])
-                for (int a = 0; a < A; ++a) {
-                    if (a == i) continue;
-                    const bool a_done = v.s_old[a] || (v.newf[a] && a < i);
-                    if (!a_done && row[a] < c.sep_dist) rew -= c.collision_rew * 4;
-                }
+            // collision block (…_july.py:1117-1124) and info_callback's collision count (:780-786) in one sweep
+            int ncol_r = 0, ncol_i = 0;
+            const bool me_old = v.s_old[i] != 0, me_new = v.newf[i] != 0;
+#pragma unroll 4
+            for (int a = 0; a < A; ++a) {
+                const bool close = row[a] < c.sep_dist && a != i;
+                const int so = v.s_old[a], nf = v.newf[a];
+                ncol_r += (close && !so && !(nf && a < i)) ? 1 : 0;
+                ncol_i += (close && !so && !(nf && a <= i)) ? 1 : 0;
+            }
+            if (me_old) { ncol_r = 0; }
+            if (me_old || me_new) ncol_i = 0;
+            for (int q = 0; q < ncol_r; ++q) rew -= c.collision_rew * 4;
+            nac += ncol_i;
             const bool obst_hit = obstacle_collision_ego(p, v, i);
-            if (obst_hit) rew -= c.collision_rew * 3;
+            if (obst_hit) { rew -= c.collision_rew * 3; noc += 1; }
             double serr = 0;
             if (july) {
                 const double tdx = v.tube[T_EXX] - v.tube[T_ENTX], tdy = v.tube[T_EXY] - v.tube[T_ENTY];
@@ -505,10 +551,11 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
                 const double ux = tdx / tlen, uy = tdy / tlen;
                 const double qx = px - v.tube[T_ENTX], qy = py - v.tube[T_ENTY];
                 const double proj = qx * ux + qy * uy;
-                const double edist = norm2(qx - proj * tdx, qy - proj * tdy);      // un-normalised (:1154)
                 if (cp == prevA + 1 && phase_reached == cp - 1) {
-                    if (cp == 1 && 0 <= proj && proj < 0.1 * tlen && edist < 0.2 * tlen) rew += c.goal_rew * 3;
-                    else if (cp == 2) rew += c.goal_rew * 3;
+                    if (cp == 1) {
+                        const double edist = norm2(qx - proj * tdx, qy - proj * tdy);   // un-normalised (:1154)
+                        if (0 <= proj && proj < 0.1 * tlen && edist < 0.2 * tlen) rew += c.goal_rew * 3;
+                    } else if (cp == 2) rew += c.goal_rew * 3;
                 }
                 if (cp == 0) rew -= norm2(v.tube[T_ENTX] - px, v.tube[T_ENTY] - py);
                 else if (cp == 1) {
@@ -528,7 +575,7 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
                     sic += 1;
                 } else if (cp == 2 && phase_reached == 0) cp = 0;
                 else {
-                    if (dgoal < c.goal_thresh) { if (v.newf[i]) rew += c.goal_rew * 5; }
+                    if (dgoal < c.goal_thresh) { if (me_new) rew += c.goal_rew * 5; }
                     else rew -= dgoal;
                 }
                 if (phase_reached == 1 && cp == 0) conf += 1;
@@ -537,22 +584,19 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
                 if (cp < phase_reached) rew -= c.collision_rew;
                 prev_phase = cp;
             } else {
-                if (dgoal < c.goal_thresh) { if (v.newf[i]) rew += c.goal_rew * 5; }
+                if (dgoal < c.goal_thresh) { if (me_new) rew += c.goal_rew * 5; }
                 else rew -= dgoal;
             }
             rew = clipd(rew, -4 * c.collision_rew, c.goal_rew * 5);
             rew = clipd(rew, c.min_reward, c.max_reward);
             v.serr[i] = serr; v.rew[i] = rew;
-            const bool st = v.s_old[i] || v.newf[i];
-            done = st || cur_step >= c.episode_length;                   // _get_done environment.py:264-271
+            done = me_old || me_new || cur_step >= c.episode_length;     // _get_done environment.py:264-271
 
             // ---- info counters that depend on own data only (…_july.py:744-773)
             v.dtg_o[i] = dtg; v.trq_o[i] = trq;
-            int nearest = 0; double dmin = 0;
-            for (int q = 0; q < L; ++q) {
-                const double d = row[A + q];
-                if (q == 0 || d < dmin) { dmin = d; nearest = q; }
-            }
+            int nearest = 0; double dmin = INF;
+#pragma unroll 4
+            for (int q = 0; q < L; ++q) { const double d = row[A + q]; const bool lt = d < dmin; dmin = lt ? d : dmin; nearest = lt ? q : nearest; }
             const double thr = c.goal_thresh;
             const int tnow = (int)((double)cur_step * c.dt);
             if (dmin < thr && (nearest != greached && greached != -1)) { greached = nearest; dleft = (int)dmin; }
@@ -562,61 +606,56 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
             if (dmin < thr && nearest == greached) { dleft = (int)dmin; greached = nearest; }
             v.dtg_n[i] = dtg; v.trq_n[i] = trq;
             v.sv_n[i] = sv; v.sv_o[i] = sv - (serr > 0 ? 1 : 0);
-            if (obst_hit) noc += 1;                                      // info_callback :778-779
+            // adjacency mask of this step (…_july.py:1627-1648): done agents, reached landmarks
+            const int aoff = (me_old || me_new) ? 1 : 0, loff = (v.gt[i] == i) ? 1 : 0;
+            v.moff[i] = aoff; v.moff[A + i] = loff;
         }
         // all agents of an env done -> the worker resets it (env_wrappers.py:865-870)
         bool all_done = false;
         if (tid < 64) {
             const unsigned long long dbal = __ballot(ag && done);
+            const unsigned long long mbal = __ballot(ag && (v.moff[i] | v.moff[A + i]));
             all_done = ag && ((dbal & emask) == emask);
-            if (ag && i == 0) v.flags[0] = all_done;
+            if (ag && i == 0) { v.flags[0] = all_done; v.flags[2] = (mbal & emask) != 0ull; }
         }
         __syncthreads();
         STAMP(6);
 
         // ---- 4. info (sequential view: agents j<=i already updated, j>i not yet), outputs, write-back
         if (ag) {
-            const double* row = v.Dm + (size_t)i * E;
-            const bool me_done = v.s_old[i] || v.newf[i];
-            if (!me_done)
-                for (int a = 0; a < A; ++a) {
-                    if (a == i) continue;
-                    const bool a_done = v.s_old[a] || (v.newf[a] && a <= i);
-                    if (!a_done && row[a] < c.sep_dist) nac += 1;
-                }
             double rsum = 0;
             if (c.collaborative) for (int a = 0; a < A; ++a) rsum += v.rew[a];
             if (p.o.reward) p.o.reward[na] = (float)(c.collaborative ? rsum : rew);
             if (p.o.done) p.o.done[na] = done ? 1 : 0;
-            const double dsp0 = p.s.delta_spacing[n];
             if (p.o.info) {
-                double dm = 0, tm = 0, svsum = 0, dsp = dsp0;
+                // the counters are small integers: sums in integer arithmetic are exact in any order
+                long long sd = 0, st = 0, sdd = 0, stt = 0; int ssv = 0;
+#pragma unroll 4
                 for (int a = 0; a < A; ++a) {
-                    dm += a <= i ? v.dtg_n[a] : v.dtg_o[a];
-                    tm += a <= i ? v.trq_n[a] : v.trq_o[a];
-                    svsum += a <= i ? v.sv_n[a] : v.sv_o[a];
+                    const bool nw = a <= i;
+                    const long long dd = nw ? v.dtg_n[a] : v.dtg_o[a], tt = nw ? v.trq_n[a] : v.trq_o[a];
+                    sd += dd; st += tt; sdd += dd * dd; stt += tt * tt;
+                    ssv += nw ? v.sv_n[a] : v.sv_o[a];
                 }
-                for (int a = 0; a <= i; ++a) dsp += v.serr[a];          // same order as the list append
-                dm /= A; tm /= A;
-                double dv = 0, tv = 0;
-                for (int a = 0; a < A; ++a) {
-                    const double pq = (a <= i ? v.dtg_n[a] : v.dtg_o[a]) - dm, qq = (a <= i ? v.trq_n[a] : v.trq_o[a]) - tm;
-                    dv += pq * pq; tv += qq * qq;
-                }
-                const double ds = sqrt(dv / A), ts = sqrt(tv / A);
+                double dsp = dsp0;
+                if (july) for (int a = 0; a <= i; ++a) dsp += v.serr[a];   // same order as the list append (:1180)
+                const double dm = (double)sd / A, tm = (double)st / A;
+                // population variance = (A*sum(x^2) - sum(x)^2) / A^2, numerator exact
+                const double dvn = (double)((long long)A * sdd - sd * sd), tvn = (double)((long long)A * stt - st * st);
+                const double ds = sqrt(dvn) / A, ts = sqrt(tvn) / A;
                 float* o = p.o.info + na * GMPE_INFO_KEYS;
                 o[0] = (float)rew; o[1] = (float)dleft; o[2] = (float)trq; o[3] = (float)nac; o[4] = (float)noc;
                 o[5] = (float)dm; o[6] = (float)ds; o[7] = (float)(dm / (ds + 0.0001)); o[8] = (float)dtg;
                 o[9] = (float)trq; o[10] = (float)tm; o[11] = (float)ts; o[12] = (float)(tm / (ts + 0.0001));
                 o[13] = (float)((double)conf / c.episode_length);
-                o[14] = (float)(dsp / (svsum != 0 ? svsum : 1));
+                o[14] = (float)(dsp / (ssv != 0 ? (double)ssv : 1.0));
                 o[15] = (float)((double)sv / (sic != 0 ? sic : 1));
                 o[16] = (float)gmt;
             }
             if (!all_done) {                                            // persist the stepped state
                 if (i == 0) {
                     double dsp = dsp0;
-                    for (int a = 0; a < A; ++a) dsp += v.serr[a];
+                    if (july) for (int a = 0; a < A; ++a) dsp += v.serr[a];
                     p.s.delta_spacing[n] = dsp;
                     p.s.rng_ctr[n] = ctr0 + v.flags[1];
                     p.s.current_step[n] = cur_step;
@@ -630,13 +669,12 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
                 p.s.spacing_viol[na] = sv; p.s.steps_in_corr[na] = sic; p.s.conformance[na] = conf;
             }
         }
-        __syncthreads();
         STAMP(7);
     }
 
     // ---- 5. reset (explicit, or the worker's auto-reset when every agent of the env is done)
-    int any_reset = 0;
-    for (int gg = 0; gg < Gv; ++gg) any_reset |= l.flags[gg * 4 + 0];     // block-uniform
+    int any_reset = 0, any_mask = 0;
+    for (int gg = 0; gg < Gv; ++gg) { any_reset |= l.flags[gg * 4 + 0]; any_mask |= l.flags[gg * 4 + 2]; }   // block-uniform
     if (any_reset) {
         const bool mine = ag && v.flags[0];
         if (mine && i == 0) {                                             // one lane per resetting env
@@ -645,13 +683,14 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
             p.s.rng_ctr[n] = ctr;
             p.s.current_step[n] = 0;
             p.s.delta_spacing[n] = 0.0;
+            v.flags[2] = 0;
         }
         __syncthreads();
         if (mine) {
             v.s2[i] = v.n2[i]; v.s3[i] = v.n3[i];
             double vx, vy; vel_of(c, v.n2[i], v.n3[i], vx, vy);
             v.vox[i] = v.vnx[i] = vx; v.voy[i] = v.vny[i] = vy;
-            v.s_old[i] = 0; v.newf[i] = 0; v.gt[i] = -1;
+            v.s_old[i] = 0; v.newf[i] = 0; v.gt[i] = -1; v.moff[i] = 0; v.moff[A + i] = 0;
             int prevA = prev_phase, ph = 0;
             if (july) ph = phase_eval(v.tube, v.ex[i], v.ey[i], prev_phase, prevA);   // reset-time observation (:1447)
             prev_phase = prevA;
@@ -667,38 +706,26 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
             ph1 = ph;
         }
         __syncthreads();                                                // positions of all agents final
-        distance_rows<BLOCK>(p, l, Gv, tid, true);
+        distance_pass<BLOCK>(p, l, Gv, tid, true);
+        static_block<BLOCK>(p, l, Gv, tid, true);
         __syncthreads();
         if (mine) write_obs(p, v, i, v.vox[i], v.voy[i], ph1);
+        any_mask = 0;
+        for (int gg = 0; gg < Gv; ++gg) any_mask |= l.flags[gg * 4 + 2];
     }
     if (ag && err) atomicOr(&p.s.error_flags[n], err);
-    __syncthreads();
     STAMP(8);
 
+    // ---- 6. adjacency mask (…_july.py:1627-1648): rows/cols of done agents and reached landmarks -> 0.
+    // Only tiles that contain such an entity pay for this pass.
     const int abl = p.ablate;
-    // ---- 6. masked distance matrix (calculate_distances core.py:600-624 + mask …_july.py:1627-1648), fp32 in LDS
-    const int EE = E * E, EE4 = (EE + 3) / 4 * 4, AD4 = (A * D + 3) / 4 * 4;
-    if (!(abl & 4))
-    for (int q = tid; q < Gv * EE; q += BLOCK) {
-        const int gg = fdiv(q, EE, p.m_EE), rc = q - gg * EE, r = fdiv(rc, E, p.m_E), cc = rc - r * E;
-        const int ab = gg * A, eb = gg * E;
-        double d = 0.0;
-        if (r != cc) {
-            if (r < A) d = l.Dm[(size_t)gg * A * E + r * E + cc];
-            else if (cc < A) d = l.Dm[(size_t)gg * A * E + cc * E + r];
-            else {
-                const int a = r < cc ? r : cc, b = r < cc ? cc : r;
-                const double dx = l.ex[eb + a] - l.ex[eb + b], dy = l.ey[eb + a] - l.ey[eb + b];
-                d = sqrt(dx * dx + dy * dy);
-            }
-            bool off = false;
-            if (r < A) off |= (l.s_old[ab + r] | l.newf[ab + r]) != 0;
-            if (cc < A) off |= (l.s_old[ab + cc] | l.newf[ab + cc]) != 0;
-            if (r >= A && r < A + L) off |= (r - A < A && l.gt[ab + r - A] == r - A);
-            if (cc >= A && cc < A + L) off |= (cc - A < A && l.gt[ab + cc - A] == cc - A);
-            if (off) d = 0.0;
+    if (any_mask && !(abl & 4)) {
+        for (int q = tid; q < Gv * EE; q += BLOCK) {
+            const int gg = fdiv(q, EE, p.m_EE), rc = q - gg * EE;
+            if (!l.flags[gg * 4 + 2]) continue;
+            const int r = fdiv(rc, E, p.m_E), cc = rc - r * E;
+            if (l.moff[gg * E + r] | l.moff[gg * E + cc]) l.M[(size_t)gg * EE4 + rc] = 0.0f;
         }
-        l.M[(size_t)gg * EE4 + rc] = (float)d;
     }
     __syncthreads();
     STAMP(9);
@@ -714,7 +741,7 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
                     const int gg = fdiv(q, nq, p.m_nq), m = q - gg * nq;
                     if (l.flags[gg * 4 + 3]) reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(l.M + (size_t)gg * EE4)[m];
                 }
-            } else for (int q = tid; q < Gv * EE; q += BLOCK) { const int gg = q / EE; if (l.flags[gg * 4 + 3]) dst[q] = l.M[(size_t)gg * EE4 + (q - gg * EE)]; }
+            } else for (int q = tid; q < Gv * EE; q += BLOCK) { const int gg = fdiv(q, EE, p.m_EE); if (l.flags[gg * 4 + 3]) dst[q] = l.M[(size_t)gg * EE4 + (q - gg * EE)]; }
         } else {
             float* dst = p.o.adj + (size_t)n0 * A * EE;
             if (vec) {
@@ -725,11 +752,13 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
                     if (!l.flags[gg * 4 + 3]) continue;
                     const float4 val = reinterpret_cast<const float4*>(l.M + (size_t)gg * EE4)[m];
                     float4* d4 = reinterpret_cast<float4*>(dst) + (size_t)gg * A * nq + m;
+#pragma unroll 2
                     for (int a = 0; a < A; ++a) d4[(size_t)a * nq] = val;
                 }
             } else {
-                for (int q = tid; q < Gv * A * EE; q += BLOCK) {
-                    const int gg = q / (A * EE), rc = (q - gg * A * EE) % EE;
+                const int AEE = A * EE;
+                for (int q = tid; q < Gv * AEE; q += BLOCK) {
+                    const int gg = q / AEE, rem = q - gg * AEE, rc = rem % EE;    // rare path (E*E % 4 != 0): plain division
                     if (l.flags[gg * 4 + 3]) dst[q] = l.M[(size_t)gg * EE4 + rc];
                 }
             }
@@ -737,29 +766,38 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
     }
     STAMP(10);
     if (p.o.node_obs && !(abl & 2)) {
-        // node row (ego i, entity k) = 2 float4: [rel_vel, rel_pos] and [rel_goal, occupied, type]
-        float4* dst = reinterpret_cast<float4*>(p.o.node_obs + (size_t)n0 * A * E * GMPE_NODE_FEATS);
-        const int per_env = A * E * 2;
-        for (int q = tid; q < Gv * per_env; q += BLOCK) {
-            const int gg = fdiv(q, per_env, p.m_pe), rem = q - gg * per_env;
+        // node row (ego, entity k) = 2 float4: [rel_vel, rel_pos] and [rel_goal, occupied, type].
+        // A lane owns one (env, entity, half) slot, keeps that entity's data in registers and walks the egos.
+        float4* base = reinterpret_cast<float4*>(p.o.node_obs + (size_t)n0 * A * E * GMPE_NODE_FEATS);
+        const int E2 = 2 * E;
+        for (int sidx = tid; sidx < Gv * E2; sidx += BLOCK) {
+            const int gg = fdiv(sidx, E2, p.m_2E), rem = sidx - gg * E2;
             if (!l.flags[gg * 4 + 3]) continue;
-            const int half = rem & 1, row = rem >> 1;
-            const int ei = fdiv(row, E, p.m_E), k = row - ei * E;
+            const int k = rem >> 1, half = rem & 1;
             const int ab = gg * A, eb = gg * E;
-            const double px = l.ex[eb + ei], py = l.ey[eb + ei];
-            const double rx = l.ex[eb + k] - px, ry = l.ey[eb + k] - py;
-            float4 val;
-            if (half == 0) {
-                const bool en = l.newf[ab + ei] != 0;
-                const double evx = en ? l.vnx[ab + ei] : l.vox[ab + ei], evy = en ? l.vny[ab + ei] : l.voy[ab + ei];
-                double kvx = 0.0, kvy = 0.0;
-                if (k < A) { const bool post = l.newf[ab + k] && k <= ei; kvx = post ? l.vnx[ab + k] : l.vox[ab + k]; kvy = post ? l.vny[ab + k] : l.voy[ab + k]; }
-                val = make_float4((float)(kvx - evx), (float)(kvy - evy), (float)rx, (float)ry);
-            } else {
-                if (k < A) val = make_float4((float)(l.ex[eb + A + k] - px), (float)(l.ey[eb + A + k] - py), 0.0f, 0.0f);
-                else val = make_float4((float)rx, (float)ry, 1.0f, k < A + L ? 1.0f : 2.0f);
+            const double kx = l.ex[eb + k], ky = l.ey[eb + k];
+            const bool kag = k < A;
+            const int kk = kag ? k : 0;
+            const double kvox = kag ? l.vox[ab + kk] : 0.0, kvoy = kag ? l.voy[ab + kk] : 0.0;
+            const double kvnx = kag ? l.vnx[ab + kk] : 0.0, kvny = kag ? l.vny[ab + kk] : 0.0;
+            const bool knew = kag && l.newf[ab + kk] != 0;
+            const double gx = kag ? l.ex[eb + A + kk] : kx, gy = kag ? l.ey[eb + A + kk] : ky;
+            const float occ = kag ? 0.0f : 1.0f, typ = kag ? 0.0f : (k < A + L ? 1.0f : 2.0f);
+            float4* dst = base + (size_t)gg * A * E2 + rem;
+#pragma unroll 2
+            for (int ei = 0; ei < A; ++ei) {
+                const double px = l.ex[eb + ei], py = l.ey[eb + ei];
+                float4 val;
+                if (half == 0) {
+                    const bool en = l.newf[ab + ei] != 0;
+                    const double evx = en ? l.vnx[ab + ei] : l.vox[ab + ei], evy = en ? l.vny[ab + ei] : l.voy[ab + ei];
+                    const bool post = knew && k <= ei;
+                    val = make_float4((float)((post ? kvnx : kvox) - evx), (float)((post ? kvny : kvoy) - evy), (float)(kx - px), (float)(ky - py));
+                } else {
+                    val = make_float4((float)(gx - px), (float)(gy - py), occ, typ);
+                }
+                dst[(size_t)ei * E2] = val;
             }
-            dst[q] = val;
         }
     }
     STAMP(11);
@@ -768,7 +806,7 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
         const int AD = A * D;
         for (int q = tid; q < Gv * AD; q += BLOCK) { const int gg = fdiv(q, AD, p.m_AD); if (l.flags[gg * 4 + 3]) dst[q] = l.obs[(size_t)gg * AD4 + (q - gg * AD)]; }
     }
-    if (p.o.agent_id) for (int q = tid; q < Gv * A; q += BLOCK) { const int gg = q / A; if (l.flags[gg * 4 + 3]) p.o.agent_id[(size_t)n0 * A + q] = q - gg * A; }   // get_id :1554
+    if (p.o.agent_id) for (int q = tid; q < Gv * A; q += BLOCK) { const int gg = fdiv(q, A, p.m_A); if (l.flags[gg * 4 + 3]) p.o.agent_id[(size_t)n0 * A + q] = q - gg * A; }   // get_id :1554
     STAMP(12);
 }
 
@@ -963,20 +1001,25 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     // distance pass and the stores. GMPE_G / GMPE_BLOCK override the heuristic (tuning, tests).
     const char* env_g = getenv("GMPE_G");
     const char* env_block = getenv("GMPE_BLOCK");
-    int G = env_g ? atoi(env_g) : 64 / h->A;
+    // Heuristic (measured on MI355X, profiles/README.md): the per-agent passes are a dependent fp64 chain of
+    // ~25 us, so the kernel wants >= ~2 single-wave tiles per SIMD in flight before it packs more envs per tile.
+    int G = env_g ? atoi(env_g) : (int)(N / 2048);
     if (G < 1) G = 1;
     if (G > 64 / h->A) G = 64 / h->A;
+    if (G < 1) G = 1;
     if (G > (int)N) G = (int)N;
     while (G > 1 && lds_bytes(G, h->A, E, h->D) > 48 * 1024) --G;
     {   // exact magic division (fdiv) needs q*d < 2^32 for every (range, divisor) pair the kernel uses
-        const uint64_t AE = (uint64_t)h->A * E, EE = (uint64_t)E * E;
-        const uint64_t worst = (uint64_t)G * (2 * AE > EE ? 2 * AE : EE) * (2 * AE > EE ? 2 * AE : EE);
-        if (worst >= (1ull << 32) || (uint64_t)G * h->A * EE * h->A * EE >= (1ull << 40)) { gmpe_destroy(h); return fail(GMPE_ERR_UNSUPPORTED, "tile too large for the index arithmetic"); }
+        const uint64_t S = (uint64_t)h->L + h->O;
+        uint64_t d = (uint64_t)h->A * E;
+        const uint64_t cand[] = {(uint64_t)E * E, S * S, (uint64_t)h->A * (h->A + h->O), (uint64_t)h->A * h->D, 2ull * E};
+        for (uint64_t x : cand) if (x > d) d = x;
+        if ((uint64_t)G * d * d >= (1ull << 32)) { gmpe_destroy(h); return fail(GMPE_ERR_UNSUPPORTED, "tile too large for the index arithmetic"); }
     }
     h->G = G;
     h->ablate = getenv("GMPE_ABLATE") ? atoi(getenv("GMPE_ABLATE")) : 0;
     const size_t stream_f4 = (size_t)G * h->A * ((size_t)E * E / 4 + 2 * (size_t)E);
-    h->block = env_block ? atoi(env_block) : (stream_f4 <= 2048 ? 64 : (stream_f4 <= 8192 ? 128 : 256));
+    h->block = env_block ? atoi(env_block) : (stream_f4 <= 4096 ? 64 : (stream_f4 <= 16384 ? 128 : 256));
     if (h->block != 64 && h->block != 128 && h->block != 256) h->block = 256;
     const size_t lds = lds_bytes(h->G, h->A, E, h->D);
     if (lds > 160 * 1024) { gmpe_destroy(h); return fail(GMPE_ERR_UNSUPPORTED, "per-tile LDS exceeds 160 KiB"); }
@@ -1061,6 +1104,8 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
     p.m_E = magic_of(p.E); p.m_AE = magic_of(p.A * p.E); p.m_EE = magic_of(p.E * p.E); p.m_nq = magic_of(p.E * p.E / 4);
     p.m_2E = magic_of(2 * p.E); p.m_pe = magic_of(p.A * p.E * 2); p.m_AD = magic_of(p.A * p.D); p.m_A = magic_of(p.A);
     p.m_L = magic_of(p.L); p.m_O = magic_of(p.O);
+    p.m_S = magic_of(p.L + p.O); p.m_SS = magic_of((p.L + p.O) * (p.L + p.O)); p.m_C = magic_of(p.A + p.O);
+    p.m_AC = magic_of(p.A * (p.A + p.O)); p.m_AEE = magic_of(p.A * p.E * p.E);
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t lds = lds_bytes(h->G, h->A, h->E, h->D);

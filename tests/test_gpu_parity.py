@@ -272,3 +272,61 @@ def test_full_size_properties_c3():
     live = row != 0
     assert torch.allclose(row[live], d[live], atol=1e-5)
     eng.check_errors()
+
+
+# ---------------------------------------------------------------- other shapes / variants
+def test_c4_shape_obstacles_walls_vs_oracle():
+    """BASELINE configs[3] shape: 32 agents + 8 obstacles + 4 walls (E = 72), small N."""
+    cfg = gmpe.make_config(scenario_name="navigation_graph", num_envs=12, num_agents=32, num_obstacles=8,
+                           num_walls=4, world_size=8.0, episode_length=6, seed=21)
+    assert _rollout_vs_oracle(cfg, 14, seed=6) >= 12
+
+
+def test_c5_shape_64_agents_vs_oracle():
+    """BASELINE configs[4] shape: 64 agents / 64 landmarks (E = 128): one env per tile, >64 KiB LDS."""
+    cfg = gmpe.make_config(scenario_name="navigation_graph", num_envs=5, num_agents=64, world_size=12.0,
+                           episode_length=5, seed=22)
+    assert _rollout_vs_oracle(cfg, 11, seed=7) >= 5
+
+
+def test_july_64_agents_vs_oracle():
+    cfg = gmpe.make_config(num_envs=3, num_agents=64, world_size=30.0, episode_length=4, seed=23)
+    _rollout_vs_oracle(cfg, 9, seed=8)
+
+
+def test_unicycle_constants_vs_oracle():
+    cfg = gmpe.make_config(dynamics_type="unicycle_vehicle", num_envs=32, num_agents=4, world_size=4.0,
+                           episode_length=15, seed=24)
+    _rollout_vs_oracle(cfg, 32, seed=9)
+
+
+def test_nine_action_double_integrator_and_collaborative_reward():
+    cfg = gmpe.make_config(scenario_name="navigation_graph", num_envs=32, num_agents=5, num_obstacles=1,
+                           total_actions=9, collaborative=True, world_size=3.0, episode_length=10, seed=25)
+    _rollout_vs_oracle(cfg, 22, seed=10)
+
+
+def test_odd_entity_count_scalar_store_path():
+    """E*E not a multiple of 4 (E = 7): the adjacency falls back to scalar stores."""
+    cfg = gmpe.make_config(scenario_name="navigation_graph", num_envs=20, num_agents=3, num_obstacles=1,
+                           world_size=3.0, episode_length=7, seed=26)
+    assert cfg.num_entities == 7
+    _rollout_vs_oracle(cfg, 16, seed=11)
+
+
+def test_tile_shapes_give_identical_results(monkeypatch):
+    """G (envs per workgroup) and BLOCK are pure performance knobs."""
+    import torch
+    outs = []
+    for G, B in ((1, 64), (3, 128), (6, 256)):
+        monkeypatch.setenv("GMPE_G", str(G)); monkeypatch.setenv("GMPE_BLOCK", str(B))
+        eng = _engine(gmpe.make_config(num_envs=50, num_agents=10, seed=31, episode_length=7))
+        eng.reset()
+        g = torch.Generator(); g.manual_seed(3)
+        for t in range(16):
+            o = eng.step(torch.randint(0, 25, (50, 10), generator=g, dtype=torch.int32))
+        outs.append([x.clone() for x in (o.obs, o.node_obs, o.adj, o.reward, o.done, o.info)])
+        eng.close()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)

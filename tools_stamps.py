@@ -22,11 +22,19 @@ lib.gmpe_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 buf = np.zeros((8192, 16), dtype=np.uint64)
 nb = lib.gmpe_debug_stamps(eng.h, buf.ctypes.data_as(C.c_void_p), 8192)
 s = buf[:nb].astype(np.int64)
-names = ["load", "pre-dist", "dynamics", "sync+write", "post-dist", "phase/draw", "obs/reward", "info/persist", "reset", "M", "adj", "node", "obs+id"]
+names = ["0 load", "1a F-pass", "1b dynamics", "dist+static", "2 phase/draw", "3 obs/reward", "4 info/persist", "5 reset", "6 mask", "7 adj", "7 node", "7 obs+id", "-"]
 d = np.diff(s[:, :13], axis=1)
 print("blocks", nb, "G/BLOCK env:", os.environ.get("GMPE_G"), os.environ.get("GMPE_BLOCK"))
 tot = (s[:, 12] - s[:, 0])
 print("total cycles/block: median %d  p90 %d" % (np.median(tot), np.percentile(tot, 90)))
 for k, nme in enumerate(names[:12]):
     print("%-14s median %7d  mean %8.0f" % (nme, np.median(d[:, k]), d[:, k].mean()))
-print("span first-start..last-end: %d cycles" % (s[:, 12].max() - s[:, 0].min()))
+ok = s[:, 0] > 0
+t0 = s[ok, 0].min()
+print("span first-start..last-end: %d cycles; starts p50 %d p99 %d max %d; ends p1 %d p50 %d" % (
+    s[ok, 12].max() - t0, np.percentile(s[ok, 0] - t0, 50), np.percentile(s[ok, 0] - t0, 99), (s[ok, 0] - t0).max(),
+    np.percentile(s[ok, 12] - t0, 1), np.percentile(s[ok, 12] - t0, 50)))
+eng.timing(True); eng.timing_read()
+for k in range(20): eng.step(acts[k])
+ms, nl = eng.timing_read()
+print("event-timed kernel: %.1f us" % (ms / nl * 1e3))
