@@ -162,19 +162,36 @@ __device__ inline void decode_action(const gmpe_config& c, int idx, double& u0, 
 
 // Scenario.observation (…_july.py:1337-1463) for ego i into the LDS staging row; `phase` = value of
 // the first get_agent_phase call of the step. Uses the PRE-reward own velocity (vox/voy).
-__device__ inline void write_obs(const KParams& p, const Lds& l, int i, double vx, double vy, int phase) {
+template <int AP>
+__device__ __forceinline__ void write_obs(const KParams& p, const Lds& l, int i, double vx, double vy, int phase) {
     float* o = l.obs + (size_t)i * p.D;
     const double px = l.ex[i], py = l.ey[i];
     const double gx = l.ex[p.A + i] - px, gy = l.ey[p.A + i] - py;
     o[0] = (float)px; o[1] = (float)py; o[2] = (float)vx; o[3] = (float)vy;
     o[4] = (float)gx; o[5] = (float)gy; o[6] = 0.0f; o[7] = (float)gx; o[8] = (float)gy;
-    int b1 = -1, b2 = -1; double d1 = 0, d2 = 0;                   // stable two-smallest (1398-1417)
+    // stable two-smallest of the other agents (1398-1417): strict '<' keeps the first of equal distances
+    const double INF = __builtin_huge_val();
+    int b1 = -1, b2 = -1; double d1 = INF, d2 = INF;
     const double* row = l.Dm + (size_t)i * p.E;
-    for (int k = 0; k < p.A; ++k) {
-        if (k == i) continue;
-        const double d = row[k];
-        if (b1 < 0 || d < d1) { b2 = b1; d2 = d1; b1 = k; d1 = d; }
-        else if (b2 < 0 || d < d2) { b2 = k; d2 = d; }
+    if (AP) {
+        double rv[AP ? AP : 1];
+#pragma unroll
+        for (int k = 0; k < AP; ++k) rv[k] = row[k < p.A ? k : 0];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < AP; ++k) {
+            const double d = (k < p.A && k != i) ? rv[k] : INF;
+            const bool lt1 = d < d1, lt2 = d < d2;
+            d2 = lt1 ? d1 : (lt2 ? d : d2); b2 = lt1 ? b1 : (lt2 ? k : b2);
+            d1 = lt1 ? d : d1; b1 = lt1 ? k : b1;
+        }
+    } else {
+        for (int k = 0; k < p.A; ++k) {
+            const double d = k != i ? row[k] : INF;
+            const bool lt1 = d < d1, lt2 = d < d2;
+            d2 = lt1 ? d1 : (lt2 ? d : d2); b2 = lt1 ? b1 : (lt2 ? k : b2);
+            d1 = lt1 ? d : d1; b1 = lt1 ? k : b1;
+        }
     }
     o[9] = b1 >= 0 ? (float)(l.ex[b1] - px) : 0.f; o[10] = b1 >= 0 ? (float)(l.ey[b1] - py) : 0.f;
     o[11] = b2 >= 0 ? (float)(l.ex[b2] - px) : 0.f; o[12] = b2 >= 0 ? (float)(l.ey[b2] - py) : 0.f;
@@ -314,7 +331,11 @@ __device__ __forceinline__ void static_block(const KParams& p, const Lds& l, int
 #endif
 
 // ---------------------------------------------------------------- the fused kernel
-template <int BLOCK>
+// AP > 0: compile-time bound (A, L <= AP) for the per-agent sweeps, so they unroll fully and every LDS read of a
+// sweep is issued before the first use (the sweeps are latency-bound: one wave per SIMD, ~100-cycle LDS reads).
+// Out-of-range iterations read a clamped index and are masked in the arithmetic. AP == 0: run-time bounds.
+#define SWEEP(var, n) _Pragma("unroll") for (int var = 0; var < (AP ? AP : (n)); ++var)
+template <int BLOCK, int AP>
 __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -348,29 +369,21 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
     int64_t ctr0 = 0;
 
     STAMP(0);
-    // ---- 0. load state (every global read of the step happens here, in one batch)
-    for (int q = tid; q < Gv * GMPE_TUBE_STRIDE; q += BLOCK) l.tube[q] = p.s.tube[(size_t)n0 * GMPE_TUBE_STRIDE + q];
-    for (int q = tid; q < Gv * L; q += BLOCK) {
-        const int gg = fdiv(q, L, p.m_L), k = q - gg * L;
-        l.ex[gg * E + A + k] = p.s.landmarks[((size_t)n0 * L + q) * 2]; l.ey[gg * E + A + k] = p.s.landmarks[((size_t)n0 * L + q) * 2 + 1];
-    }
-    for (int q = tid; q < Gv * O; q += BLOCK) {
-        const int gg = fdiv(q, O, p.m_O), k = q - gg * O;
-        l.ex[gg * E + A + L + k] = p.s.obstacles[((size_t)n0 * O + q) * 2]; l.ey[gg * E + A + L + k] = p.s.obstacles[((size_t)n0 * O + q) * 2 + 1];
-    }
-    for (int q = tid; q < G * E; q += BLOCK) l.moff[q] = 0;
-    if (tid < G) {
-        const int nn = n0 + tid;
-        const bool active = nn < N && (step || !p.mask || p.mask[nn]);
-        l.flags[tid * 4 + 0] = (!step && active); l.flags[tid * 4 + 1] = 0; l.flags[tid * 4 + 2] = 0; l.flags[tid * 4 + 3] = active;
-    }
+    // ---- 0. load state. Every global read of the step is ISSUED here before any of them is consumed
+    // (first iteration of each staging loop hoisted into registers), so the tile pays one HBM round trip.
+    const bool t_ok = tid < Gv * GMPE_TUBE_STRIDE, l_ok = tid < Gv * L, o_ok = tid < Gv * O;
+    double tube0 = 0, lmx0 = 0, lmy0 = 0, obx0 = 0, oby0 = 0;
+    if (t_ok) tube0 = p.s.tube[(size_t)n0 * GMPE_TUBE_STRIDE + tid];
+    if (l_ok) { lmx0 = p.s.landmarks[((size_t)n0 * L + tid) * 2]; lmy0 = p.s.landmarks[((size_t)n0 * L + tid) * 2 + 1]; }
+    if (o_ok) { obx0 = p.s.obstacles[((size_t)n0 * O + tid) * 2]; oby0 = p.s.obstacles[((size_t)n0 * O + tid) * 2 + 1]; }
+    double x0 = 0, y0 = 0, a20 = 0, a30 = 0; int st0 = 0, gt0 = -1;
     if (ag) {
         prev_phase = p.s.prev_phase[na];
         cur_step = p.s.current_step[n];
         ctr0 = p.s.rng_ctr[n];
         if (step) {
-            v.ex[i] = p.s.x[na]; v.ey[i] = p.s.y[na]; v.s2[i] = p.s.s2[na]; v.s3[i] = p.s.s3[na];
-            v.s_old[i] = p.s.status[na]; v.gt[i] = p.s.goal_tracker[na];
+            x0 = p.s.x[na]; y0 = p.s.y[na]; a20 = p.s.s2[na]; a30 = p.s.s3[na];
+            st0 = p.s.status[na]; gt0 = p.s.goal_tracker[na];
             phase_reached = p.s.phase_reached[na]; cooldown = p.s.cooldown[na];
             p_dist = p.s.p_dist[na]; tim = p.s.time[na];
             trq = p.s.times_required[na]; dtg = p.s.dists_to_goal[na]; dleft = p.s.dist_left[na];
@@ -384,13 +397,36 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
                 float best = oh[0];
                 for (int q = 1; q < c.n_actions; ++q) { const float x = oh[q]; if (x > best) { best = x; act_idx = q; } }
             }
-            act_idx = act_idx < 0 ? 0 : (act_idx >= c.n_actions ? c.n_actions - 1 : act_idx);
         }
+    }
+    for (int q = tid; q < G * E; q += BLOCK) l.moff[q] = 0;
+    if (tid < G) {
+        const int nn = n0 + tid;
+        const bool active = nn < N && (step || !p.mask || p.mask[nn]);
+        l.flags[tid * 4 + 0] = (!step && active); l.flags[tid * 4 + 1] = 0; l.flags[tid * 4 + 2] = 0; l.flags[tid * 4 + 3] = active;
+    }
+    if (t_ok) l.tube[tid] = tube0;
+    for (int q = tid + BLOCK; q < Gv * GMPE_TUBE_STRIDE; q += BLOCK) l.tube[q] = p.s.tube[(size_t)n0 * GMPE_TUBE_STRIDE + q];
+    if (l_ok) { const int gg = fdiv(tid, L, p.m_L), k = tid - gg * L; l.ex[gg * E + A + k] = lmx0; l.ey[gg * E + A + k] = lmy0; }
+    for (int q = tid + BLOCK; q < Gv * L; q += BLOCK) {
+        const int gg = fdiv(q, L, p.m_L), k = q - gg * L;
+        l.ex[gg * E + A + k] = p.s.landmarks[((size_t)n0 * L + q) * 2]; l.ey[gg * E + A + k] = p.s.landmarks[((size_t)n0 * L + q) * 2 + 1];
+    }
+    if (o_ok) { const int gg = fdiv(tid, O, p.m_O), k = tid - gg * O; l.ex[gg * E + A + L + k] = obx0; l.ey[gg * E + A + L + k] = oby0; }
+    for (int q = tid + BLOCK; q < Gv * O; q += BLOCK) {
+        const int gg = fdiv(q, O, p.m_O), k = q - gg * O;
+        l.ex[gg * E + A + L + k] = p.s.obstacles[((size_t)n0 * O + q) * 2]; l.ey[gg * E + A + L + k] = p.s.obstacles[((size_t)n0 * O + q) * 2 + 1];
+    }
+    if (ag && step) {
+        v.ex[i] = x0; v.ey[i] = y0; v.s2[i] = a20; v.s3[i] = a30; v.s_old[i] = st0; v.gt[i] = gt0;
+        act_idx = act_idx < 0 ? 0 : (act_idx >= c.n_actions ? c.n_actions - 1 : act_idx);
     }
     __syncthreads();
     STAMP(1);
 
-    int ph1 = 0;
+    int ph1 = 0, cp = 0, prevA = 0;
+    bool goal_branch = true, done = false, all_done = false;
+    double dgoal = 0, rew = 0;
     if (step) {
         cur_step += 1;
         const int C = A + O;                                            // colliders: agents + obstacles (landmarks collide=False)
@@ -446,12 +482,13 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
                 double sx = 1.0 * u0, sy = 1.0 * u1;
                 const double* fxg = Fx + (size_t)g * A * C; const double* fyg = Fy + (size_t)g * A * C;
                 const bool ego_live = v.s_old[i] == 0;                  // done side gets no agent-agent force (899-900)
-#pragma unroll 4
-                for (int k = 0; k < A; ++k) {
-                    const bool below = k < i;
-                    const int idx = below ? k * C + i : i * C + k;
+                SWEEP(k, A) {
+                    const bool ok = !AP || k < A;
+                    const int kc = ok ? k : 0;
+                    const bool below = kc < i;
+                    const int idx = below ? kc * C + i : i * C + kc;
                     const double fx = fxg[idx], fy = fyg[idx];
-                    const bool use = ego_live && k != i && (fx != 0.0 || fy != 0.0);
+                    const bool use = ok && ego_live && kc != i && (fx != 0.0 || fy != 0.0);
                     sx = use ? ((below ? -fx : fx) + sx) : sx;
                     sy = use ? ((below ? -fy : fy) + sy) : sy;
                 }
@@ -484,9 +521,7 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
         STAMP(4);
 
         // ---- 2. phase FSM + who newly reaches the goal (depends only on own data: SURVEY §8a)
-        int cp = 0, prevA = prev_phase;
-        bool goal_branch = true;
-        double dgoal = 0;
+        prevA = prev_phase;
         if (ag) {
             const double px = v.ex[i], py = v.ey[i];
             double vx, vy; vel_of(c, v.s2[i], v.s3[i], vx, vy);
@@ -516,31 +551,59 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
                     v.vnx[i] = vx; v.vny[i] = vy;
                 } else { v.n2[i] = v.s2[i]; v.n3[i] = v.s3[i]; v.vnx[i] = v.vox[i]; v.vny[i] = v.voy[i]; }
                 if (i == 0) v.flags[1] = kin ? __popcll(bal & emask) : 0;   // draws consumed (DI reset_velocity draws none)
+                // done flag (_get_done environment.py:264-271) and this step's adjacency mask (…_july.py:1627-1648:
+                // done agents, reached landmarks) depend only on status / goal_tracker: known before the rewards
+                const bool st_now = v.s_old[i] || v.newf[i];
+                done = st_now || cur_step >= c.episode_length;
+                v.moff[i] = st_now ? 1 : 0; v.moff[A + i] = (v.gt[i] == i) ? 1 : 0;
             }
+            // all agents of an env done -> the worker resets it (env_wrappers.py:865-870)
+            const unsigned long long dbal = __ballot(ag && done);
+            const unsigned long long mbal = __ballot(ag && (v.moff[i] | v.moff[A + i]));
+            all_done = ag && ((dbal & emask) == emask);
+            if (ag && i == 0) { v.flags[0] = all_done; v.flags[2] = (mbal & emask) != 0ull; }
         }
         __syncthreads();
         STAMP(5);
+    }
 
+    // Sections 3+4 as one unit: in tiles without a reset they run AFTER the graph stores were issued, so the
+    // reward / info arithmetic overlaps the HBM write drain.
+    auto sections34 = [&]() __attribute__((always_inline)) {
         // ---- 3. obs, reward, done (ego i sees agent k done iff s_old[k] || (new[k] && k < i))
-        double rew = 0; bool done = false;
+        rew = 0;
         if (ag) {
             const double px = v.ex[i], py = v.ey[i];
             const double* row = v.Dm + (size_t)i * E;
-            write_obs(p, v, i, v.vox[i], v.voy[i], ph1);
+            write_obs<AP>(p, v, i, v.vox[i], v.voy[i], ph1);
+            STAMP(13);
             // collision block (…_july.py:1117-1124) and info_callback's collision count (:780-786) in one sweep
             int ncol_r = 0, ncol_i = 0;
             const bool me_old = v.s_old[i] != 0, me_new = v.newf[i] != 0;
-#pragma unroll 4
-            for (int a = 0; a < A; ++a) {
-                const bool close = row[a] < c.sep_dist && a != i;
-                const int so = v.s_old[a], nf = v.newf[a];
-                ncol_r += (close && !so && !(nf && a < i)) ? 1 : 0;
-                ncol_i += (close && !so && !(nf && a <= i)) ? 1 : 0;
+            if (AP) {                                                  // all LDS reads of the sweep first, then the arithmetic
+                double rv[AP ? AP : 1]; int so[AP ? AP : 1], nf[AP ? AP : 1];
+#pragma unroll
+                for (int a = 0; a < AP; ++a) { const int ac = a < A ? a : 0; rv[a] = row[ac]; so[a] = v.s_old[ac]; nf[a] = v.newf[ac]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < AP; ++a) {
+                    const bool close = a < A && rv[a] < c.sep_dist && a != i;
+                    ncol_r += (close && !so[a] && !(nf[a] && a < i)) ? 1 : 0;
+                    ncol_i += (close && !so[a] && !(nf[a] && a <= i)) ? 1 : 0;
+                }
+            } else {
+                for (int a = 0; a < A; ++a) {
+                    const bool close = row[a] < c.sep_dist && a != i;
+                    const int so = v.s_old[a], nf = v.newf[a];
+                    ncol_r += (close && !so && !(nf && a < i)) ? 1 : 0;
+                    ncol_i += (close && !so && !(nf && a <= i)) ? 1 : 0;
+                }
             }
             if (me_old) { ncol_r = 0; }
             if (me_old || me_new) ncol_i = 0;
             for (int q = 0; q < ncol_r; ++q) rew -= c.collision_rew * 4;
             nac += ncol_i;
+            STAMP(14);
             const bool obst_hit = obstacle_collision_ego(p, v, i);
             if (obst_hit) { rew -= c.collision_rew * 3; noc += 1; }
             double serr = 0;
@@ -590,13 +653,12 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
             rew = clipd(rew, -4 * c.collision_rew, c.goal_rew * 5);
             rew = clipd(rew, c.min_reward, c.max_reward);
             v.serr[i] = serr; v.rew[i] = rew;
-            done = me_old || me_new || cur_step >= c.episode_length;     // _get_done environment.py:264-271
 
+            STAMP(15);
             // ---- info counters that depend on own data only (…_july.py:744-773)
             v.dtg_o[i] = dtg; v.trq_o[i] = trq;
             int nearest = 0; double dmin = INF;
-#pragma unroll 4
-            for (int q = 0; q < L; ++q) { const double d = row[A + q]; const bool lt = d < dmin; dmin = lt ? d : dmin; nearest = lt ? q : nearest; }
+            SWEEP(q, L) { const bool ok = !AP || q < L; const double d = ok ? row[A + (ok ? q : 0)] : INF; const bool lt = d < dmin; dmin = lt ? d : dmin; nearest = lt ? q : nearest; }
             const double thr = c.goal_thresh;
             const int tnow = (int)((double)cur_step * c.dt);
             if (dmin < thr && (nearest != greached && greached != -1)) { greached = nearest; dleft = (int)dmin; }
@@ -606,17 +668,6 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
             if (dmin < thr && nearest == greached) { dleft = (int)dmin; greached = nearest; }
             v.dtg_n[i] = dtg; v.trq_n[i] = trq;
             v.sv_n[i] = sv; v.sv_o[i] = sv - (serr > 0 ? 1 : 0);
-            // adjacency mask of this step (…_july.py:1627-1648): done agents, reached landmarks
-            const int aoff = (me_old || me_new) ? 1 : 0, loff = (v.gt[i] == i) ? 1 : 0;
-            v.moff[i] = aoff; v.moff[A + i] = loff;
-        }
-        // all agents of an env done -> the worker resets it (env_wrappers.py:865-870)
-        bool all_done = false;
-        if (tid < 64) {
-            const unsigned long long dbal = __ballot(ag && done);
-            const unsigned long long mbal = __ballot(ag && (v.moff[i] | v.moff[A + i]));
-            all_done = ag && ((dbal & emask) == emask);
-            if (ag && i == 0) { v.flags[0] = all_done; v.flags[2] = (mbal & emask) != 0ull; }
         }
         __syncthreads();
         STAMP(6);
@@ -628,20 +679,22 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
             if (p.o.reward) p.o.reward[na] = (float)(c.collaborative ? rsum : rew);
             if (p.o.done) p.o.done[na] = done ? 1 : 0;
             if (p.o.info) {
-                // the counters are small integers: sums in integer arithmetic are exact in any order
-                long long sd = 0, st = 0, sdd = 0, stt = 0; int ssv = 0;
-#pragma unroll 4
-                for (int a = 0; a < A; ++a) {
-                    const bool nw = a <= i;
-                    const long long dd = nw ? v.dtg_n[a] : v.dtg_o[a], tt = nw ? v.trq_n[a] : v.trq_o[a];
+                // the counters are small integers: their sums and sums of squares are exact in fp64 in any order
+                double sd = 0, st = 0, sdd = 0, stt = 0; int ssv = 0;
+                SWEEP(a, A) {
+                    const bool ok = !AP || a < A;
+                    const int ac = ok ? a : 0;
+                    const bool nw = ac <= i;
+                    const int dn = v.dtg_n[ac], d_o = v.dtg_o[ac], tn = v.trq_n[ac], to = v.trq_o[ac], svn = v.sv_n[ac], svo = v.sv_o[ac];
+                    const double dd = ok ? (double)(nw ? dn : d_o) : 0.0, tt = ok ? (double)(nw ? tn : to) : 0.0;
                     sd += dd; st += tt; sdd += dd * dd; stt += tt * tt;
-                    ssv += nw ? v.sv_n[a] : v.sv_o[a];
+                    ssv += ok ? (nw ? svn : svo) : 0;
                 }
                 double dsp = dsp0;
                 if (july) for (int a = 0; a <= i; ++a) dsp += v.serr[a];   // same order as the list append (:1180)
-                const double dm = (double)sd / A, tm = (double)st / A;
+                const double dm = sd / A, tm = st / A;
                 // population variance = (A*sum(x^2) - sum(x)^2) / A^2, numerator exact
-                const double dvn = (double)((long long)A * sdd - sd * sd), tvn = (double)((long long)A * stt - st * st);
+                const double dvn = (double)A * sdd - sd * sd, tvn = (double)A * stt - st * st;
                 const double ds = sqrt(dvn) / A, ts = sqrt(tvn) / A;
                 float* o = p.o.info + na * GMPE_INFO_KEYS;
                 o[0] = (float)rew; o[1] = (float)dleft; o[2] = (float)trq; o[3] = (float)nac; o[4] = (float)noc;
@@ -670,143 +723,159 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
             }
         }
         STAMP(7);
-    }
+    };
 
-    // ---- 5. reset (explicit, or the worker's auto-reset when every agent of the env is done)
     int any_reset = 0, any_mask = 0;
     for (int gg = 0; gg < Gv; ++gg) { any_reset |= l.flags[gg * 4 + 0]; any_mask |= l.flags[gg * 4 + 2]; }   // block-uniform
-    if (any_reset) {
-        const bool mine = ag && v.flags[0];
-        if (mine && i == 0) {                                             // one lane per resetting env
-            int64_t ctr = ctr0 + (step ? v.flags[1] : 0);                // this step's heading re-draws come first
-            reset_world_serial(p, v, n, ctr, err);
-            p.s.rng_ctr[n] = ctr;
-            p.s.current_step[n] = 0;
-            p.s.delta_spacing[n] = 0.0;
-            v.flags[2] = 0;
-        }
-        __syncthreads();
-        if (mine) {
-            v.s2[i] = v.n2[i]; v.s3[i] = v.n3[i];
-            double vx, vy; vel_of(c, v.n2[i], v.n3[i], vx, vy);
-            v.vox[i] = v.vnx[i] = vx; v.voy[i] = v.vny[i] = vy;
-            v.s_old[i] = 0; v.newf[i] = 0; v.gt[i] = -1; v.moff[i] = 0; v.moff[A + i] = 0;
-            int prevA = prev_phase, ph = 0;
-            if (july) ph = phase_eval(v.tube, v.ex[i], v.ey[i], prev_phase, prevA);   // reset-time observation (:1447)
-            prev_phase = prevA;
-            const double dx = v.ex[i] - v.ex[A + i], dy = v.ey[i] - v.ey[A + i];
-            gmt = c.max_speed > 0 ? sqrt(dx * dx + dy * dy) / c.max_speed : 0.0;
-            p.s.x[na] = v.ex[i]; p.s.y[na] = v.ey[i]; p.s.s2[na] = v.n2[i]; p.s.s3[na] = v.n3[i];
-            p.s.status[na] = 0; p.s.prev_phase[na] = prev_phase; p.s.phase_reached[na] = 0; p.s.cooldown[na] = 0;
-            p.s.goal_tracker[na] = -1; p.s.p_dist[na] = 0.0; p.s.time[na] = 0.0;
-            p.s.times_required[na] = -1; p.s.dists_to_goal[na] = -1; p.s.dist_left[na] = -1;
-            p.s.goal_reached[na] = -1; p.s.n_agent_coll[na] = 0; p.s.n_obst_coll[na] = 0;
-            p.s.spacing_viol[na] = 0; p.s.steps_in_corr[na] = 0; p.s.conformance[na] = 0;
-            p.s.goal_min_time[na] = gmt;
-            ph1 = ph;
-        }
-        __syncthreads();                                                // positions of all agents final
-        distance_pass<BLOCK>(p, l, Gv, tid, true);
-        static_block<BLOCK>(p, l, Gv, tid, true);
-        __syncthreads();
-        if (mine) write_obs(p, v, i, v.vox[i], v.voy[i], ph1);
-        any_mask = 0;
-        for (int gg = 0; gg < Gv; ++gg) any_mask |= l.flags[gg * 4 + 2];
-    }
-    if (ag && err) atomicOr(&p.s.error_flags[n], err);
-    STAMP(8);
-
-    // ---- 6. adjacency mask (…_july.py:1627-1648): rows/cols of done agents and reached landmarks -> 0.
-    // Only tiles that contain such an entity pay for this pass.
     const int abl = p.ablate;
-    if (any_mask && !(abl & 4)) {
-        for (int q = tid; q < Gv * EE; q += BLOCK) {
-            const int gg = fdiv(q, EE, p.m_EE), rc = q - gg * EE;
-            if (!l.flags[gg * 4 + 2]) continue;
-            const int r = fdiv(rc, E, p.m_E), cc = rc - r * E;
-            if (l.moff[gg * E + r] | l.moff[gg * E + cc]) l.M[(size_t)gg * EE4 + rc] = 0.0f;
-        }
-    }
-    __syncthreads();
-    STAMP(9);
 
-    // ---- 7. stream the observations out (16-byte stores wherever the row length allows)
-    if (p.o.adj && !(abl & 1)) {
-        const bool vec = (EE & 3) == 0;
-        if (p.o.adj_compact) {
-            float* dst = p.o.adj + (size_t)n0 * EE;
-            if (vec) {
-                const int nq = EE / 4;
-                for (int q = tid; q < Gv * nq; q += BLOCK) {
-                    const int gg = fdiv(q, nq, p.m_nq), m = q - gg * nq;
-                    if (l.flags[gg * 4 + 3]) reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(l.M + (size_t)gg * EE4)[m];
-                }
-            } else for (int q = tid; q < Gv * EE; q += BLOCK) { const int gg = fdiv(q, EE, p.m_EE); if (l.flags[gg * 4 + 3]) dst[q] = l.M[(size_t)gg * EE4 + (q - gg * EE)]; }
-        } else {
-            float* dst = p.o.adj + (size_t)n0 * A * EE;
-            if (vec) {
-                const int nq = EE / 4;
-                // each lane keeps one float4 of the env's matrix and stores it to the A ego copies
-                for (int q = tid; q < Gv * nq; q += BLOCK) {
-                    const int gg = fdiv(q, nq, p.m_nq), m = q - gg * nq;
-                    if (!l.flags[gg * 4 + 3]) continue;
-                    const float4 val = reinterpret_cast<const float4*>(l.M + (size_t)gg * EE4)[m];
-                    float4* d4 = reinterpret_cast<float4*>(dst) + (size_t)gg * A * nq + m;
-#pragma unroll 2
-                    for (int a = 0; a < A; ++a) d4[(size_t)a * nq] = val;
-                }
+    auto stream_graph = [&]() __attribute__((always_inline)) {
+        // ---- 6. adjacency mask (…_july.py:1627-1648): rows/cols of done agents and reached landmarks -> 0.
+        // Only tiles that contain such an entity pay for this pass.
+        if (any_mask && !(abl & 4)) {
+            for (int q = tid; q < Gv * EE; q += BLOCK) {
+                const int gg = fdiv(q, EE, p.m_EE), rc = q - gg * EE;
+                if (!l.flags[gg * 4 + 2]) continue;
+                const int r = fdiv(rc, E, p.m_E), cc = rc - r * E;
+                if (l.moff[gg * E + r] | l.moff[gg * E + cc]) l.M[(size_t)gg * EE4 + rc] = 0.0f;
+            }
+        }
+        __syncthreads();
+        STAMP(9);
+
+        // ---- 7. stream the observations out (16-byte stores wherever the row length allows)
+        if (p.o.adj && !(abl & 1)) {
+            const bool vec = (EE & 3) == 0;
+            if (p.o.adj_compact) {
+                float* dst = p.o.adj + (size_t)n0 * EE;
+                if (vec) {
+                    const int nq = EE / 4;
+                    for (int q = tid; q < Gv * nq; q += BLOCK) {
+                        const int gg = fdiv(q, nq, p.m_nq), m = q - gg * nq;
+                        if (l.flags[gg * 4 + 3]) reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(l.M + (size_t)gg * EE4)[m];
+                    }
+                } else for (int q = tid; q < Gv * EE; q += BLOCK) { const int gg = fdiv(q, EE, p.m_EE); if (l.flags[gg * 4 + 3]) dst[q] = l.M[(size_t)gg * EE4 + (q - gg * EE)]; }
             } else {
-                const int AEE = A * EE;
-                for (int q = tid; q < Gv * AEE; q += BLOCK) {
-                    const int gg = q / AEE, rem = q - gg * AEE, rc = rem % EE;    // rare path (E*E % 4 != 0): plain division
-                    if (l.flags[gg * 4 + 3]) dst[q] = l.M[(size_t)gg * EE4 + rc];
-                }
-            }
-        }
-    }
-    STAMP(10);
-    if (p.o.node_obs && !(abl & 2)) {
-        // node row (ego, entity k) = 2 float4: [rel_vel, rel_pos] and [rel_goal, occupied, type].
-        // A lane owns one (env, entity, half) slot, keeps that entity's data in registers and walks the egos.
-        float4* base = reinterpret_cast<float4*>(p.o.node_obs + (size_t)n0 * A * E * GMPE_NODE_FEATS);
-        const int E2 = 2 * E;
-        for (int sidx = tid; sidx < Gv * E2; sidx += BLOCK) {
-            const int gg = fdiv(sidx, E2, p.m_2E), rem = sidx - gg * E2;
-            if (!l.flags[gg * 4 + 3]) continue;
-            const int k = rem >> 1, half = rem & 1;
-            const int ab = gg * A, eb = gg * E;
-            const double kx = l.ex[eb + k], ky = l.ey[eb + k];
-            const bool kag = k < A;
-            const int kk = kag ? k : 0;
-            const double kvox = kag ? l.vox[ab + kk] : 0.0, kvoy = kag ? l.voy[ab + kk] : 0.0;
-            const double kvnx = kag ? l.vnx[ab + kk] : 0.0, kvny = kag ? l.vny[ab + kk] : 0.0;
-            const bool knew = kag && l.newf[ab + kk] != 0;
-            const double gx = kag ? l.ex[eb + A + kk] : kx, gy = kag ? l.ey[eb + A + kk] : ky;
-            const float occ = kag ? 0.0f : 1.0f, typ = kag ? 0.0f : (k < A + L ? 1.0f : 2.0f);
-            float4* dst = base + (size_t)gg * A * E2 + rem;
-#pragma unroll 2
-            for (int ei = 0; ei < A; ++ei) {
-                const double px = l.ex[eb + ei], py = l.ey[eb + ei];
-                float4 val;
-                if (half == 0) {
-                    const bool en = l.newf[ab + ei] != 0;
-                    const double evx = en ? l.vnx[ab + ei] : l.vox[ab + ei], evy = en ? l.vny[ab + ei] : l.voy[ab + ei];
-                    const bool post = knew && k <= ei;
-                    val = make_float4((float)((post ? kvnx : kvox) - evx), (float)((post ? kvny : kvoy) - evy), (float)(kx - px), (float)(ky - py));
+                float* dst = p.o.adj + (size_t)n0 * A * EE;
+                if (vec) {
+                    const int nq = EE / 4;
+                    // each lane keeps one float4 of the env's matrix and stores it to the A ego copies
+                    for (int q = tid; q < Gv * nq; q += BLOCK) {
+                        const int gg = fdiv(q, nq, p.m_nq), m = q - gg * nq;
+                        if (!l.flags[gg * 4 + 3]) continue;
+                        const float4 val = reinterpret_cast<const float4*>(l.M + (size_t)gg * EE4)[m];
+                        float4* d4 = reinterpret_cast<float4*>(dst) + (size_t)gg * A * nq + m;
+                        SWEEP(a, A) { if (!AP || a < A) d4[(size_t)a * nq] = val; }
+                    }
                 } else {
-                    val = make_float4((float)(gx - px), (float)(gy - py), occ, typ);
+                    const int AEE = A * EE;
+                    for (int q = tid; q < Gv * AEE; q += BLOCK) {
+                        const int gg = q / AEE, rem = q - gg * AEE, rc = rem % EE;    // rare path (E*E % 4 != 0): plain division
+                        if (l.flags[gg * 4 + 3]) dst[q] = l.M[(size_t)gg * EE4 + rc];
+                    }
                 }
-                dst[(size_t)ei * E2] = val;
             }
         }
+        STAMP(10);
+        if (p.o.node_obs && !(abl & 2)) {
+            // node row (ego, entity k) = 2 float4: [rel_vel, rel_pos] and [rel_goal, occupied, type].
+            // A lane owns one (env, entity, half) slot, keeps that entity's data in registers and walks the egos.
+            float4* base = reinterpret_cast<float4*>(p.o.node_obs + (size_t)n0 * A * E * GMPE_NODE_FEATS);
+            const int E2 = 2 * E;
+            for (int sidx = tid; sidx < Gv * E2; sidx += BLOCK) {
+                const int gg = fdiv(sidx, E2, p.m_2E), rem = sidx - gg * E2;
+                if (!l.flags[gg * 4 + 3]) continue;
+                const int k = rem >> 1, half = rem & 1;
+                const int ab = gg * A, eb = gg * E;
+                const double kx = l.ex[eb + k], ky = l.ey[eb + k];
+                const bool kag = k < A;
+                const int kk = kag ? k : 0;
+                const double kvox = kag ? l.vox[ab + kk] : 0.0, kvoy = kag ? l.voy[ab + kk] : 0.0;
+                const double kvnx = kag ? l.vnx[ab + kk] : 0.0, kvny = kag ? l.vny[ab + kk] : 0.0;
+                const bool knew = kag && l.newf[ab + kk] != 0;
+                const double gx = kag ? l.ex[eb + A + kk] : kx, gy = kag ? l.ey[eb + A + kk] : ky;
+                const float occ = kag ? 0.0f : 1.0f, typ = kag ? 0.0f : (k < A + L ? 1.0f : 2.0f);
+                float4* dst = base + (size_t)gg * A * E2 + rem;
+                SWEEP(ei, A) {
+                    const bool ok = !AP || ei < A;
+                    const int ec = ok ? ei : 0;
+                    const double px = l.ex[eb + ec], py = l.ey[eb + ec];
+                    const bool en = l.newf[ab + ec] != 0;
+                    const double evox = l.vox[ab + ec], evoy = l.voy[ab + ec], evnx = l.vnx[ab + ec], evny = l.vny[ab + ec];
+                    float4 val;
+                    if (half == 0) {
+                        const double evx = en ? evnx : evox, evy = en ? evny : evoy;
+                        const bool post = knew && k <= ec;
+                        val = make_float4((float)((post ? kvnx : kvox) - evx), (float)((post ? kvny : kvoy) - evy), (float)(kx - px), (float)(ky - py));
+                    } else {
+                        val = make_float4((float)(gx - px), (float)(gy - py), occ, typ);
+                    }
+                    if (ok) dst[(size_t)ec * E2] = val;
+                }
+            }
+        }
+    };
+    auto stream_small = [&]() __attribute__((always_inline)) {
+        STAMP(11);
+        if (p.o.obs) {
+            float* dst = p.o.obs + (size_t)n0 * A * D;
+            const int AD = A * D;
+            for (int q = tid; q < Gv * AD; q += BLOCK) { const int gg = fdiv(q, AD, p.m_AD); if (l.flags[gg * 4 + 3]) dst[q] = l.obs[(size_t)gg * AD4 + (q - gg * AD)]; }
+        }
+        if (p.o.agent_id) for (int q = tid; q < Gv * A; q += BLOCK) { const int gg = fdiv(q, A, p.m_A); if (l.flags[gg * 4 + 3]) p.o.agent_id[(size_t)n0 * A + q] = q - gg * A; }   // get_id :1554
+    };
+
+    // Common case (no env of the tile resets): issue the 22 KB/env of graph stores FIRST, then do the reward /
+    // info arithmetic under the HBM write drain. Tiles with a reset need the terminal reward/info before the
+    // reset overwrites the LDS state, so they keep the reference's order.
+    const bool early = step && !any_reset;
+    if (early) stream_graph();
+    if (step) { sections34(); __syncthreads(); }
+    {
+        // ---- 5. reset (explicit, or the worker's auto-reset when every agent of the env is done)
+        if (any_reset) {
+            const bool mine = ag && v.flags[0];
+            if (mine && i == 0) {                                             // one lane per resetting env
+                int64_t ctr = ctr0 + (step ? v.flags[1] : 0);                // this step's heading re-draws come first
+                reset_world_serial(p, v, n, ctr, err);
+                p.s.rng_ctr[n] = ctr;
+                p.s.current_step[n] = 0;
+                p.s.delta_spacing[n] = 0.0;
+                v.flags[2] = 0;
+            }
+            __syncthreads();
+            if (mine) {
+                v.s2[i] = v.n2[i]; v.s3[i] = v.n3[i];
+                double vx, vy; vel_of(c, v.n2[i], v.n3[i], vx, vy);
+                v.vox[i] = v.vnx[i] = vx; v.voy[i] = v.vny[i] = vy;
+                v.s_old[i] = 0; v.newf[i] = 0; v.gt[i] = -1; v.moff[i] = 0; v.moff[A + i] = 0;
+                int prevA = prev_phase, ph = 0;
+                if (july) ph = phase_eval(v.tube, v.ex[i], v.ey[i], prev_phase, prevA);   // reset-time observation (:1447)
+                prev_phase = prevA;
+                const double dx = v.ex[i] - v.ex[A + i], dy = v.ey[i] - v.ey[A + i];
+                gmt = c.max_speed > 0 ? sqrt(dx * dx + dy * dy) / c.max_speed : 0.0;
+                p.s.x[na] = v.ex[i]; p.s.y[na] = v.ey[i]; p.s.s2[na] = v.n2[i]; p.s.s3[na] = v.n3[i];
+                p.s.status[na] = 0; p.s.prev_phase[na] = prev_phase; p.s.phase_reached[na] = 0; p.s.cooldown[na] = 0;
+                p.s.goal_tracker[na] = -1; p.s.p_dist[na] = 0.0; p.s.time[na] = 0.0;
+                p.s.times_required[na] = -1; p.s.dists_to_goal[na] = -1; p.s.dist_left[na] = -1;
+                p.s.goal_reached[na] = -1; p.s.n_agent_coll[na] = 0; p.s.n_obst_coll[na] = 0;
+                p.s.spacing_viol[na] = 0; p.s.steps_in_corr[na] = 0; p.s.conformance[na] = 0;
+                p.s.goal_min_time[na] = gmt;
+                ph1 = ph;
+            }
+            __syncthreads();                                                // positions of all agents final
+            distance_pass<BLOCK>(p, l, Gv, tid, true);
+            static_block<BLOCK>(p, l, Gv, tid, true);
+            __syncthreads();
+            if (mine) write_obs<AP>(p, v, i, v.vox[i], v.voy[i], ph1);
+            any_mask = 0;
+            for (int gg = 0; gg < Gv; ++gg) any_mask |= l.flags[gg * 4 + 2];
+        }
+        STAMP(8);
     }
-    STAMP(11);
-    if (p.o.obs) {
-        float* dst = p.o.obs + (size_t)n0 * A * D;
-        const int AD = A * D;
-        for (int q = tid; q < Gv * AD; q += BLOCK) { const int gg = fdiv(q, AD, p.m_AD); if (l.flags[gg * 4 + 3]) dst[q] = l.obs[(size_t)gg * AD4 + (q - gg * AD)]; }
-    }
-    if (p.o.agent_id) for (int q = tid; q < Gv * A; q += BLOCK) { const int gg = fdiv(q, A, p.m_A); if (l.flags[gg * 4 + 3]) p.o.agent_id[(size_t)n0 * A + q] = q - gg * A; }   // get_id :1554
+    if (!early) stream_graph();
+    stream_small();
+    if (ag && err) atomicOr(&p.s.error_flags[n], err);
     STAMP(12);
 }
 
@@ -1025,9 +1094,10 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     if (lds > 160 * 1024) { gmpe_destroy(h); return fail(GMPE_ERR_UNSUPPORTED, "per-tile LDS exceeds 160 KiB"); }
     if (lds > 48 * 1024) {                                   // opt in to >64 KiB dynamic LDS (gfx950: 160 KiB per CU)
         hipError_t e = hipSuccess;
-        if (h->block == 64) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        else if (h->block == 128) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        else e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const void* fns[9] = {reinterpret_cast<const void*>(&k_env<64, 0>), reinterpret_cast<const void*>(&k_env<64, 3>), reinterpret_cast<const void*>(&k_env<64, 10>),
+                              reinterpret_cast<const void*>(&k_env<128, 0>), reinterpret_cast<const void*>(&k_env<128, 3>), reinterpret_cast<const void*>(&k_env<128, 10>),
+                              reinterpret_cast<const void*>(&k_env<256, 0>), reinterpret_cast<const void*>(&k_env<256, 3>), reinterpret_cast<const void*>(&k_env<256, 10>)};
+        for (int q = 0; q < 9 && e == hipSuccess; ++q) e = hipFuncSetAttribute(fns[q], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { gmpe_destroy(h); return fail(GMPE_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
     }
 #ifdef GMPE_STAMPS
@@ -1118,10 +1188,11 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
         e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1];
         HIPCHK(hipEventRecord(e0, st));
     }
+    const int ap = (h->A == h->L && (h->A == 10 || h->A == 3)) ? h->A : 0;   // exact-size instantiations of the common cases
     switch (h->block) {
-        case 64: hipLaunchKernelGGL(k_env<64>, grid, dim3(64), lds, st, p); break;
-        case 128: hipLaunchKernelGGL(k_env<128>, grid, dim3(128), lds, st, p); break;
-        default: hipLaunchKernelGGL(k_env<256>, grid, dim3(256), lds, st, p); break;
+        case 64: if (ap == 10) hipLaunchKernelGGL((k_env<64, 10>), grid, dim3(64), lds, st, p); else if (ap == 3) hipLaunchKernelGGL((k_env<64, 3>), grid, dim3(64), lds, st, p); else hipLaunchKernelGGL((k_env<64, 0>), grid, dim3(64), lds, st, p); break;
+        case 128: if (ap == 10) hipLaunchKernelGGL((k_env<128, 10>), grid, dim3(128), lds, st, p); else if (ap == 3) hipLaunchKernelGGL((k_env<128, 3>), grid, dim3(128), lds, st, p); else hipLaunchKernelGGL((k_env<128, 0>), grid, dim3(128), lds, st, p); break;
+        default: if (ap == 10) hipLaunchKernelGGL((k_env<256, 10>), grid, dim3(256), lds, st, p); else if (ap == 3) hipLaunchKernelGGL((k_env<256, 3>), grid, dim3(256), lds, st, p); else hipLaunchKernelGGL((k_env<256, 0>), grid, dim3(256), lds, st, p); break;
     }
     HIPCHK(hipGetLastError());
     if (h->timing) { HIPCHK(hipEventRecord(e1, st)); h->ev_used += 2; }

@@ -31,6 +31,8 @@ for k, nme in enumerate(names[:12]):
     print("%-14s median %7d  mean %8.0f" % (nme, np.median(d[:, k]), d[:, k].mean()))
 ok = s[:, 0] > 0
 t0 = s[ok, 0].min()
+sec3 = s[:, [5, 13, 14, 15, 6]]
+print("section 3 split (obs | collisions | obstacle+phase+goal+clip | own-info): ", np.median(np.diff(sec3, axis=1), axis=0))
 print("span first-start..last-end: %d cycles; starts p50 %d p99 %d max %d; ends p1 %d p50 %d" % (
     s[ok, 12].max() - t0, np.percentile(s[ok, 0] - t0, 50), np.percentile(s[ok, 0] - t0, 99), (s[ok, 0] - t0).max(),
     np.percentile(s[ok, 12] - t0, 1), np.percentile(s[ok, 12] - t0, 50)))
