@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--adj-compact", action="store_true", help="write one ExE matrix per env instead of A copies")
     ap.add_argument("--no-info", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-loop", action="store_true", help="call gmpe_step from Python once per step instead of gmpe_step_many")
     ap.add_argument("--gather", action="store_true", help="also time step + RCCL all_gather of the compact rollout slab")
     args = ap.parse_args()
 
@@ -124,16 +125,29 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # ---- timed region: EXACTLY K steps, per-launch HIP events on the launch stream
-    eng.timing(True)
-    eng.timing_read(reset=True)
+    # ---- timed region: EXACTLY K steps. One HIP event pair on the LAUNCH stream brackets the K launches
+    # (recorded by libgmpe.so itself): average launch duration = elapsed / K. Per-launch event pairs are not
+    # used here because they perturb back-to-back launches (~+5 us per step, measured); they are taken in a
+    # separate short pass below for comparison with the rocprofv3 per-kernel average.
     barrier(); torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for k in range(K):
-        eng.step(actions[(W + k) % n_act_sets])
+    eng.region_mark(0)
+    if args.host_loop:
+        for k in range(K):
+            eng.step(actions[(W + k) % n_act_sets])
+    else:
+        # one C call enqueues the K launches (gmpe_step_many): no Python / ctypes round trip between steps
+        eng.step_many(actions, K)
+    eng.region_mark(1)
     torch.cuda.synchronize(dev); barrier()
     t1 = time.perf_counter()
-    kern_ms, launches = eng.timing_read(reset=True)
+    region_ms = eng.region_ms()
+    kern_ms, launches = region_ms, K
+    # separate pass: per-launch events (isolated kernel duration incl. event overhead)
+    eng.timing(True); eng.timing_read(reset=True)
+    eng.step_many(actions, min(K, 200))
+    torch.cuda.synchronize(dev)
+    iso_ms, iso_n = eng.timing_read(reset=True)
     eng.timing(False)
     eng.check_errors()
     el = t1 - t0
@@ -181,6 +195,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "gmpe::k_env", "avg_launch_ms": avg_ms, "launches": launches,
+                         "timing": "one HIP event pair on the launch stream around the K launches of the timed region",
+                         "isolated_launch_ms": iso_ms / max(1, iso_n),
                          "algorithmic_bytes_per_env_step": B, "env_steps_per_launch": n_envs},
         }
         if gather is not None:

@@ -969,6 +969,7 @@ struct gmpe_handle {
     int G = 1;                       // envs per workgroup
     int ablate = 0;
     unsigned long long* stamps = nullptr;
+    hipEvent_t region_ev[2] = {nullptr, nullptr};
     int32_t* edge_ws = nullptr;      // [2*cap_graphs] counts | offsets
     size_t edge_ws_graphs = 0;
 };
@@ -1128,6 +1129,7 @@ int gmpe_destroy(gmpe_handle* h) {
     for (void* q : h->allocs) (void)hipFree(q);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     if (h->edge_ws) (void)hipFree(h->edge_ws);
+    for (hipEvent_t e : h->region_ev) if (e) (void)hipEventDestroy(e);
     delete h;
     return GMPE_OK;
 }
@@ -1206,6 +1208,16 @@ int gmpe_step(gmpe_handle* h, const int32_t* action_idx_dev, const gmpe_outputs*
     if (!action_idx_dev) return fail(GMPE_ERR_INVALID_ARG, "gmpe_step: null actions");
     return launch(h, MODE_STEP, action_idx_dev, nullptr, nullptr, out, stream);
 }
+int gmpe_step_many(gmpe_handle* h, const int32_t* actions_dev, int32_t num_steps, int32_t num_action_sets,
+                   const gmpe_outputs* out, void* stream) {
+    if (!actions_dev || num_steps < 0 || num_action_sets < 1) return fail(GMPE_ERR_INVALID_ARG, "gmpe_step_many: bad arguments");
+    const size_t stride = (size_t)h->c.num_envs * h->A;
+    for (int32_t k = 0; k < num_steps; ++k) {
+        const int rc = launch(h, MODE_STEP, actions_dev + (size_t)(k % num_action_sets) * stride, nullptr, nullptr, out, stream);
+        if (rc) return rc;
+    }
+    return GMPE_OK;
+}
 int gmpe_step_onehot(gmpe_handle* h, const float* onehot_dev, const gmpe_outputs* out, void* stream) {
     if (!onehot_dev) return fail(GMPE_ERR_INVALID_ARG, "gmpe_step_onehot: null actions");
     return launch(h, MODE_STEP, nullptr, onehot_dev, nullptr, out, stream);
@@ -1235,6 +1247,22 @@ int gmpe_edges_from_adj(gmpe_handle* h, const float* adj_dev, int32_t batch, int
     return GMPE_OK;
 }
 
+int gmpe_timing_mark(gmpe_handle* h, int32_t which, void* stream) {
+    if (!h || which < 0 || which > 1) return fail(GMPE_ERR_INVALID_ARG, "gmpe_timing_mark: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->region_ev[which]) HIPCHK(hipEventCreate(&h->region_ev[which]));
+    HIPCHK(hipEventRecord(h->region_ev[which], static_cast<hipStream_t>(stream)));
+    return GMPE_OK;
+}
+int gmpe_timing_region_ms(gmpe_handle* h, double* ms) {
+    if (!h || !ms || !h->region_ev[0] || !h->region_ev[1]) return fail(GMPE_ERR_INVALID_ARG, "gmpe_timing_region_ms: region not marked");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventSynchronize(h->region_ev[1]));
+    float f = 0;
+    HIPCHK(hipEventElapsedTime(&f, h->region_ev[0], h->region_ev[1]));
+    *ms = f;
+    return GMPE_OK;
+}
 int gmpe_timing_enable(gmpe_handle* h, int32_t enable) {
     if (!h) return fail(GMPE_ERR_INVALID_ARG, "null handle");
     h->timing = enable != 0;

@@ -87,6 +87,18 @@ class GmpeEngine(object):
         _lib.check(self.lib.gmpe_step(self.h, a.data_ptr(), C.byref(self._o), self._stream()), "gmpe_step")
         return self.out
 
+    def step_many(self, action_sets, num_steps):
+        """Open-loop rollout: `num_steps` steps enqueued by one C call; step k uses action_sets[k % len]
+        (int32 device tensor [S, N, A]). Returns the outputs of the LAST step."""
+        a = action_sets
+        if a.dtype != torch.int32 or not a.is_contiguous() or a.device != self.device or a.dim() != 3:
+            raise ValueError("action_sets must be a contiguous int32 device tensor [S, N, A]")
+        if a.shape[1] * a.shape[2] != self.N * self.A:
+            raise ValueError("action_sets must be [S, %d, %d]" % (self.N, self.A))
+        _lib.check(self.lib.gmpe_step_many(self.h, a.data_ptr(), int(num_steps), int(a.shape[0]), C.byref(self._o),
+                                           self._stream()), "gmpe_step_many")
+        return self.out
+
     def step_onehot(self, onehot):
         """onehot: float32 device tensor [N,A,n_actions] (argmax fused into the kernel)."""
         a = onehot
@@ -158,6 +170,15 @@ class GmpeEngine(object):
         ms, n = C.c_double(), C.c_int64()
         _lib.check(self.lib.gmpe_timing_read(self.h, C.byref(ms), C.byref(n), int(reset)), "gmpe_timing_read")
         return ms.value, n.value
+
+    def region_mark(self, which):
+        """HIP event on the launch stream: which=0 before the first launch of a region, 1 after the last."""
+        _lib.check(self.lib.gmpe_timing_mark(self.h, int(which), self._stream()), "gmpe_timing_mark")
+
+    def region_ms(self):
+        ms = C.c_double()
+        _lib.check(self.lib.gmpe_timing_region_ms(self.h, C.byref(ms)), "gmpe_timing_region_ms")
+        return ms.value
 
     @property
     def bytes_per_env_step(self):

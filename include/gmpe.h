@@ -186,6 +186,13 @@ int gmpe_reset(gmpe_handle* h, const uint8_t* env_mask_dev, const gmpe_outputs* 
  * environment.py:446). */
 int gmpe_step(gmpe_handle* h, const int32_t* action_idx_dev, const gmpe_outputs* out, void* stream);
 
+/* `num_steps` consecutive steps enqueued by one call (no host round trip between launches): step k uses
+ * action set k % num_action_sets of `actions_dev` (i32 [num_action_sets, N, A]). Outputs are overwritten
+ * by every step (same buffers), exactly as a host loop over gmpe_step would. Used for open-loop rollouts
+ * (random-action benchmarking, scripted policies). */
+int gmpe_step_many(gmpe_handle* h, const int32_t* actions_dev, int32_t num_steps, int32_t num_action_sets,
+                   const gmpe_outputs* out, void* stream);
+
 /* Same, taking the runner's float one-hot [N,A,n_actions] (graph_mpe_runner.py:375-377); the
  * argmax (np.argmax: first maximum) is fused into the step kernel. */
 int gmpe_step_onehot(gmpe_handle* h, const float* onehot_dev, const gmpe_outputs* out, void* stream);
@@ -206,8 +213,12 @@ int gmpe_edges_from_adj(gmpe_handle* h, const float* adj_dev, int32_t batch, int
 
 /* Timing hooks used by bench.py: HIP events on the handle's launch stream around every step
  * kernel, so the dominant kernel's duration is measured live (not via torch's current stream). */
-int gmpe_timing_enable(gmpe_handle* h, int32_t enable);
+int gmpe_timing_enable(gmpe_handle* h, int32_t enable);          /* one event pair around EVERY launch (perturbs back-to-back launches by ~5 us each) */
 int gmpe_timing_read(gmpe_handle* h, double* total_ms, int64_t* launches, int32_t reset_counters);
+/* one event pair around a REGION of launches: mark(0) before the first, mark(1) after the last, both on
+ * the launch stream; region_ms synchronises on the second event. */
+int gmpe_timing_mark(gmpe_handle* h, int32_t which, void* stream);
+int gmpe_timing_region_ms(gmpe_handle* h, double* ms);
 
 #ifdef __cplusplus
 }

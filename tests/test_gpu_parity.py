@@ -330,3 +330,19 @@ def test_tile_shapes_give_identical_results(monkeypatch):
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.equal(a, b)
+
+
+def test_step_many_equals_host_loop():
+    import torch
+    cfg = gmpe.make_config(scenario_name="navigation_graph", num_envs=40, num_agents=10, seed=8, episode_length=9)
+    e1, e2 = _engine(cfg), _engine(cfg)
+    e1.reset(); e2.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    acts = torch.randint(0, 5, (7, 40, 10), generator=g, device="cuda", dtype=torch.int32)
+    for k in range(23):
+        o1 = e1.step(acts[k % 7])
+    o2 = e2.step_many(acts, 23)
+    for k in ("obs", "node_obs", "adj", "reward", "done", "info"):
+        assert torch.equal(getattr(o1, k), getattr(o2, k)), k
+    for f in ("x", "y", "s2", "s3", "rng_ctr", "current_step"):
+        np.testing.assert_array_equal(e1.get(f), e2.get(f))
