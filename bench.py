@@ -97,8 +97,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # backend "nccl" IS RCCL on ROCm. GMPE_BENCH_REHEARSAL=1: gloo + every rank on device 0, to rehearse the
+        # multi-process path on a one-GPU box (never used for reported numbers).
+        rehearsal = os.environ.get("GMPE_BENCH_REHEARSAL") == "1"
+        if rehearsal:
+            local_rank = 0
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -151,8 +158,9 @@ def main():
     eng.timing(False)
     eng.check_errors()
     el = t1 - t0
+    red_dev = dev if (dist is not None and dist.get_backend() == "nccl") else torch.device("cpu")
     if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        t = torch.tensor([el], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
@@ -167,7 +175,7 @@ def main():
         for k in range(K):
             rg.step_and_gather(actions[(W + k) % n_act_sets])
         torch.cuda.synchronize(dev); barrier()
-        tg = torch.tensor([time.perf_counter() - tg0], dtype=torch.float64, device=dev)
+        tg = torch.tensor([time.perf_counter() - tg0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         gather = {"value": world * n_envs * K / float(tg.item()), "unit": "env-steps/s",
                   "what": "step + RCCL all_gather of the compact rollout slab (obs, node_obs, ExE adj, reward, done)"}

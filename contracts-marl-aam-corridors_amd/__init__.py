@@ -13,7 +13,7 @@ __all__ = ["config", "make_config", "config_from_args"]
 
 def __getattr__(name):
     # torch / HIP-dependent modules are imported on first use
-    if name in ("engine", "vec_env", "spaces", "_lib", "sharding"):
+    if name in ("engine", "vec_env", "spaces", "_lib", "sharding", "rollout"):
         import importlib
         return importlib.import_module("." + name, __name__)
     if name in ("BatchedGraphMPEVecEnv", "GraphMPEEnv", "make_train_env"):

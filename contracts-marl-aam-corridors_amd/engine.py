@@ -54,6 +54,18 @@ class GmpeEngine(object):
         return _lib.GmpeOutputs(p(o.obs), p(o.agent_id), p(o.node_obs), p(o.adj), p(o.reward), p(o.done),
                                 p(o.info), int(self.adj_compact), 0)
 
+    def rebind(self, outputs):
+        """Point the engine at other caller-owned output tensors (same shapes/dtypes, same device)."""
+        ref = self.out
+        for k in StepOutputs.__slots__:
+            a, b = getattr(ref, k), getattr(outputs, k)
+            if (a is None) != (b is None):
+                raise ValueError("output %r: presence differs" % k)
+            if a is not None and (tuple(a.shape) != tuple(b.shape) or a.dtype != b.dtype or b.device != self.device or not b.is_contiguous()):
+                raise ValueError("output %r must be a contiguous %s tensor of shape %s on %s" % (k, a.dtype, tuple(a.shape), self.device))
+        self.out = outputs
+        self._o = self._pack(outputs)
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 

@@ -1,0 +1,93 @@
+"""DeviceRolloutBuffer — env-side arrays of GraphReplayBuffer kept in HBM.
+
+Mirrors the storage the runner fills from the env (onpolicy/utils/graph_buffer.py:84-164 shapes,
+:168-251 insert, :253-283 after_update; masks as computed in
+onpolicy/runner/shared/graph_mpe_runner.py:384-428): `[T+1, N, A, ...]` float32/int32 slots for
+obs / share_obs / node_obs / adj / agent_id / share_agent_id / masks / active_masks and `[T, N, A, 1]`
+rewards. The engine's output pointers are re-bound to slot t+1 before every step, so the kernel writes
+the rollout in place: no host hop and no device-to-device copy of the 16 KB/env adjacency.
+Policy-side fields (rnn states, values, log-probs, actions) stay with the learner.
+"""
+import torch
+
+from .config import NODE_FEATS
+from .engine import StepOutputs
+
+
+class DeviceRolloutBuffer(object):
+    def __init__(self, engine, episode_length, use_centralized_V=True):
+        self.engine = engine
+        self.T = int(episode_length)
+        self.use_centralized_V = bool(use_centralized_V)
+        c, dev = engine.cfg, engine.device
+        N, A, E, D = c.num_envs, c.num_agents, c.num_entities, c.obs_dim
+        T1 = self.T + 1
+        f32, i32 = torch.float32, torch.int32
+        self.obs = torch.zeros((T1, N, A, D), dtype=f32, device=dev)
+        self.node_obs = torch.zeros((T1, N, A, E, NODE_FEATS), dtype=f32, device=dev)
+        adj_shape = (T1, N, E, E) if engine.adj_compact else (T1, N, A, E, E)
+        self._adj = torch.zeros(adj_shape, dtype=f32, device=dev)
+        self.agent_id = torch.zeros((T1, N, A, 1), dtype=i32, device=dev)
+        self.rewards = torch.zeros((self.T, N, A, 1), dtype=f32, device=dev)
+        self.dones = torch.zeros((self.T, N, A), dtype=torch.uint8, device=dev)
+        self.masks = torch.ones((T1, N, A, 1), dtype=f32, device=dev)
+        self.active_masks = torch.ones((T1, N, A, 1), dtype=f32, device=dev)
+        self.info = torch.zeros_like(engine.out.info) if engine.out.info is not None else None
+        self.step = 0
+
+    # ------------------------------------------------------------------ views with the reference's shapes
+    @property
+    def adj(self):
+        """[T+1, N, A, E, E]; a zero-copy broadcast when the engine writes the compact matrix."""
+        if self.engine.adj_compact:
+            T1, N, E, _ = self._adj.shape
+            return self._adj[:, :, None].expand(T1, N, self.engine.A, E, E)
+        return self._adj
+
+    @property
+    def share_obs(self):
+        """graph_mpe_runner.py:408-413: every agent sees the concatenation of all agents' obs."""
+        T1, N, A, D = self.obs.shape
+        if not self.use_centralized_V:
+            return self.obs
+        return self.obs.reshape(T1, N, 1, A * D).expand(T1, N, A, A * D)
+
+    @property
+    def share_agent_id(self):
+        T1, N, A, _ = self.agent_id.shape
+        if not self.use_centralized_V:
+            return self.agent_id
+        return self.agent_id.reshape(T1, N, 1, A).expand(T1, N, A, A)
+
+    # ------------------------------------------------------------------ filling
+    def _bind(self, slot, reward_slot):
+        e = self.engine
+        o = StepOutputs(obs=self.obs[slot], agent_id=self.agent_id[slot], node_obs=self.node_obs[slot],
+                        adj=self._adj[slot],
+                        reward=self.rewards[reward_slot].view(e.N, e.A) if reward_slot is not None else e.out.reward,
+                        done=self.dones[reward_slot] if reward_slot is not None else e.out.done, info=self.info)
+        e.rebind(o)
+
+    def warmup(self):
+        """GMPERunner.warmup (graph_mpe_runner.py:213-238): reset outputs go to slot 0."""
+        self._bind(0, None)
+        self.engine.reset()
+        self.step = 0
+
+    def insert_step(self, action_idx):
+        """One env step written straight into slot step+1 (+ masks), GraphReplayBuffer.insert semantics."""
+        t = self.step
+        self._bind(t + 1, t)
+        self.engine.step(action_idx)
+        dones = self.dones[t].bool()
+        m = (~dones).to(torch.float32).unsqueeze(-1)                       # masks[dones] = 0
+        self.masks[t + 1].copy_(m)
+        dones_env = dones.all(dim=1, keepdim=True)                         # active_masks[dones_env] = 1
+        self.active_masks[t + 1].copy_((~dones | dones_env).to(torch.float32).unsqueeze(-1))
+        self.step = (t + 1) % self.T
+        return self.engine.out
+
+    def after_update(self):
+        """graph_buffer.py:253-283: the last slot becomes slot 0 of the next rollout."""
+        for buf in (self.obs, self.node_obs, self._adj, self.agent_id, self.masks, self.active_masks):
+            buf[0].copy_(buf[-1])
