@@ -41,7 +41,7 @@ struct KParams {
     int G;                    // envs per workgroup (G*A <= 64)
     int ablate;               // debug: timing-only builds of the kernel skip parts (GMPE_ABLATE)
     // magic multipliers for exact unsigned division by run-time constants (q < 2^22): floor(q/d) = umulhi(q, m)
-    uint32_t m_E, m_AE, m_EE, m_nq, m_2E, m_pe, m_AD, m_A, m_L, m_O, m_S, m_SS, m_C, m_AC, m_AEE;
+    uint32_t m_E, m_AE, m_EE, m_nq, m_2E, m_pe, m_AD, m_A, m_L, m_O, m_S, m_SS, m_C, m_AC, m_AEE, m_W, m_Sx, m_FW;
     unsigned long long* stamps;   // diagnostic build only (-DGMPE_STAMPS): [grid][16] s_memtime per phase
 };
 __host__ __device__ inline uint32_t magic_of(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(0x100000000ull / d) + 1u; }
@@ -64,6 +64,7 @@ struct Lds {
     int *dtg_o, *dtg_n, *trq_o, *trq_n, *sv_o, *sv_n;   // [G][A] info counters old/new
     int *flags;                       // [G][4]  0: reset this env, 1: heading draws this step, 2: env has masked nodes, 3: env active
     int *moff;                        // [G][E]  adjacency mask per node (done agent / reached landmark)
+    int *ptab;                        // [A(A-1)/2] agent pairs (a<<8 | k), a < k, shared by the G envs of the tile
     float *obs;                       // [G][A*D] staging
     float *M;                         // [G][E*E] masked distance matrix, fp32
 };
@@ -71,7 +72,7 @@ __host__ __device__ inline size_t lds_bytes(int G, int A, int E, int D) {
     const size_t EE4 = ((size_t)E * E + 3) / 4 * 4, AD4 = ((size_t)A * D + 3) / 4 * 4;
     size_t d = (size_t)G * (2 * E + 10 * A + 12 + (size_t)A * E);   // doubles
     size_t f = (size_t)G * (EE4 + AD4);                             // floats
-    size_t i = (size_t)G * (9 * A + 4 + E);                         // ints
+    size_t i = (size_t)G * (9 * A + 4 + E) + (size_t)A * (A - 1) / 2 + 1;   // ints
     return d * 8 + 16 + f * 4 + ((i * 4 + 15) / 16) * 16 + 32;
 }
 __device__ inline Lds carve(char* base, int G, int A, int E, int D) {
@@ -90,7 +91,7 @@ __device__ inline Lds carve(char* base, int G, int A, int E, int D) {
     int* i = reinterpret_cast<int*>(f);
     l.s_old = i; i += G * A; l.newf = i; i += G * A; l.gt = i; i += G * A;
     l.dtg_o = i; i += G * A; l.dtg_n = i; i += G * A; l.trq_o = i; i += G * A; l.trq_n = i; i += G * A;
-    l.sv_o = i; i += G * A; l.sv_n = i; i += G * A; l.flags = i; i += G * 4; l.moff = i;
+    l.sv_o = i; i += G * A; l.sv_n = i; i += G * A; l.flags = i; i += G * 4; l.moff = i; i += G * E; l.ptab = i;
     return l;
 }
 // view of env g inside the workgroup tile
@@ -104,7 +105,7 @@ __device__ inline Lds env_view(const Lds& l, int g, int A, int E, int D) {
     v.Dm = l.Dm + (size_t)g * A * E;
     v.s_old = l.s_old + g * A; v.newf = l.newf + g * A; v.gt = l.gt + g * A;
     v.dtg_o = l.dtg_o + g * A; v.dtg_n = l.dtg_n + g * A; v.trq_o = l.trq_o + g * A; v.trq_n = l.trq_n + g * A;
-    v.sv_o = l.sv_o + g * A; v.sv_n = l.sv_n + g * A; v.flags = l.flags + g * 4; v.moff = l.moff + g * E;
+    v.sv_o = l.sv_o + g * A; v.sv_n = l.sv_n + g * A; v.flags = l.flags + g * 4; v.moff = l.moff + g * E; v.ptab = l.ptab;
     v.obs = l.obs + g * AD4; v.M = l.M + g * EE4;
     return v;
 }
@@ -296,16 +297,25 @@ __device__ void reset_world_serial(const KParams& p, const Lds& l, int n, int64_
 template <int BLOCK>
 __device__ __forceinline__ void distance_pass(const KParams& p, const Lds& l, int G, int tid, bool only_reset) {
     const int A = p.A, E = p.E, AE = A * E, EE4 = (E * E + 3) / 4 * 4;
-    for (int q = tid; q < G * AE; q += BLOCK) {
-        const int g = fdiv(q, AE, p.m_AE), rc = q - g * AE, r = fdiv(rc, E, p.m_E), cc = rc - r * E;
+    const int NP = A * (A - 1) / 2, S = E - A, AS = A * S, W = NP + AS;   // per env: agent pairs + agent x static entities
+    for (int q = tid; q < G * W; q += BLOCK) {
+        const int g = fdiv(q, W, p.m_W), w = q - g * W;
         if (only_reset && !l.flags[g * 4 + 0]) continue;
-        const int a = r < cc ? r : cc, b = r < cc ? cc : r;
-        const double dx = l.ex[g * E + a] - l.ex[g * E + b], dy = l.ey[g * E + a] - l.ey[g * E + b];
-        const double d = r != cc ? sqrt(dx * dx + dy * dy) : 0.0;
-        l.Dm[q] = d;
+        int r, cc;
+        if (w < NP) { const int pk = l.ptab[w]; r = pk >> 8; cc = pk & 255; }
+        else { const int t = w - NP; r = fdiv(t, S, p.m_Sx); cc = A + (t - r * S); }
+        const double dx = l.ex[g * E + r] - l.ex[g * E + cc], dy = l.ey[g * E + r] - l.ey[g * E + cc];   // r < cc always
+        const double d = sqrt(dx * dx + dy * dy);
+        double* Dg = l.Dm + (size_t)g * AE;
         float* Mg = l.M + (size_t)g * EE4;
-        Mg[rc] = (float)d;
-        if (cc >= A) Mg[cc * E + r] = (float)d;
+        const float df = (float)d;
+        Dg[r * E + cc] = d; Mg[r * E + cc] = df; Mg[cc * E + r] = df;
+        if (cc < A) Dg[cc * E + r] = d;
+    }
+    for (int q = tid; q < G * A; q += BLOCK) {                           // diagonal
+        const int g = fdiv(q, A, p.m_A), r = q - g * A;
+        if (only_reset && !l.flags[g * 4 + 0]) continue;
+        l.Dm[(size_t)g * AE + r * E + r] = 0.0; l.M[(size_t)g * EE4 + r * E + r] = 0.0f;
     }
 }
 template <int BLOCK>
@@ -400,6 +410,10 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
         }
     }
     for (int q = tid; q < G * E; q += BLOCK) l.moff[q] = 0;
+    for (int q = tid; q < A * A; q += BLOCK) {                          // agent-pair table (a < k), row-major triangular order
+        const int a = fdiv(q, A, p.m_A), k = q - a * A;
+        if (k > a) l.ptab[a * A - a * (a + 1) / 2 + (k - a - 1)] = (a << 8) | k;
+    }
     if (tid < G) {
         const int nn = n0 + tid;
         const bool active = nn < N && (step || !p.mask || p.mask[nn]);
@@ -435,20 +449,21 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
         if (!kin) {
             // ---- 1a. contact forces, one PAIR per lane (get_entity_collision_force core.py:872-906): pair (a, k>a)
             // computed once with delta = pos[a]-pos[k]; side a gets +F, side k gets -F (summed in 1b).
-            const int AC = A * C;
-            for (int q = tid; q < Gv * AC; q += BLOCK) {
-                const int gg = fdiv(q, AC, p.m_AC), rc = q - gg * AC, a = fdiv(rc, C, p.m_C), kk = rc - a * C;
+            const int NP = A * (A - 1) / 2, W = NP + A * O;            // valid pairs only: agent pairs (a<k) + agent x obstacle
+            for (int q = tid; q < Gv * W; q += BLOCK) {
+                const int gg = fdiv(q, W, p.m_FW), w = q - gg * W;
+                int a, kk;
+                if (w < NP) { const int pk = l.ptab[w]; a = pk >> 8; kk = pk & 255; }
+                else { const int t = w - NP; a = fdiv(t, O, p.m_O); kk = A + (t - a * O); }
+                const int k = kk < A ? kk : L + kk;                     // entity index of collider kk
+                const double dx = l.ex[gg * E + a] - l.ex[gg * E + k], dy = l.ey[gg * E + a] - l.ey[gg * E + k];
+                const double dist = sqrt(dx * dx + dy * dy);
                 double fx = 0.0, fy = 0.0;
-                if (kk > a) {
-                    const int k = kk < A ? kk : L + kk;                 // entity index of collider kk
-                    const double dx = l.ex[gg * E + a] - l.ex[gg * E + k], dy = l.ey[gg * E + a] - l.ey[gg * E + k];
-                    const double dist = sqrt(dx * dx + dy * dy);
-                    if (dist < c.sep_dist + 50.0 * c.contact_margin) {  // else softplus < 1e-21: below one ulp of the sum
-                        const double pen = logaddexp0(-(dist - c.sep_dist) / c.contact_margin) * c.contact_margin;
-                        fx = c.contact_force * dx / dist * pen; fy = c.contact_force * dy / dist * pen;
-                    }
+                if (dist < c.sep_dist + 50.0 * c.contact_margin) {      // else softplus < 1e-21: below one ulp of the sum
+                    const double pen = logaddexp0(-(dist - c.sep_dist) / c.contact_margin) * c.contact_margin;
+                    fx = c.contact_force * dx / dist * pen; fy = c.contact_force * dy / dist * pen;
                 }
-                Fx[q] = fx; Fy[q] = fy;
+                Fx[(size_t)gg * A * C + a * C + kk] = fx; Fy[(size_t)gg * A * C + a * C + kk] = fy;
             }
             __syncthreads();
         }
@@ -1178,6 +1193,7 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
     p.m_L = magic_of(p.L); p.m_O = magic_of(p.O);
     p.m_S = magic_of(p.L + p.O); p.m_SS = magic_of((p.L + p.O) * (p.L + p.O)); p.m_C = magic_of(p.A + p.O);
     p.m_AC = magic_of(p.A * (p.A + p.O)); p.m_AEE = magic_of(p.A * p.E * p.E);
+    p.m_W = magic_of(p.A * (p.A - 1) / 2 + p.A * (p.E - p.A)); p.m_Sx = magic_of(p.E - p.A); p.m_FW = magic_of(p.A * (p.A - 1) / 2 + p.A * p.O);
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t lds = lds_bytes(h->G, h->A, h->E, h->D);

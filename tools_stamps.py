@@ -22,8 +22,12 @@ lib.gmpe_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 buf = np.zeros((8192, 16), dtype=np.uint64)
 nb = lib.gmpe_debug_stamps(eng.h, buf.ctypes.data_as(C.c_void_p), 8192)
 s = buf[:nb].astype(np.int64)
-names = ["0 load", "1a F-pass", "1b dynamics", "dist+static", "2 phase/draw", "3 obs/reward", "4 info/persist", "5 reset", "6 mask", "7 adj", "7 node", "7 obs+id", "-"]
+names = ["S0 load", "S1 F-pass", "S2 dynamics", "S3 dist+static", "S4 phase/draw", "S5", "S6", "S7", "S8", "S9", "S10", "S11", "-"]
 d = np.diff(s[:, :13], axis=1)
+# v3 order in non-reset tiles: S0..S5 (load, F, dyn, dist, phase), then S9 (mask) S10 (adj) -> node -> S13/14/15 sec3 -> S6 -> sec4 -> S7 -> S11 obs -> S12
+def seg(a, b): return np.median(s[:, b] - s[:, a])
+print("v3 timeline (median cycles): load %d | F %d | dyn %d | dist %d | phase %d | mask %d | adj %d | node %d | sec3 %d | sec4 %d | obs-store %d | total %d" % (
+    seg(0,1), seg(1,2), seg(2,3), seg(3,4), seg(4,5), seg(5,9), seg(9,10), seg(10,13), seg(13,6), seg(6,7), seg(7,12), seg(0,12)))
 print("blocks", nb, "G/BLOCK env:", os.environ.get("GMPE_G"), os.environ.get("GMPE_BLOCK"))
 tot = (s[:, 12] - s[:, 0])
 print("total cycles/block: median %d  p90 %d" % (np.median(tot), np.percentile(tot, 90)))
