@@ -250,3 +250,10 @@ def test_oracle_navigation_graph_invariants():
         sp = np.hypot(o.get("s2"), o.get("s3"))
         assert (sp <= cfg.max_speed + 1e-12).all()
     assert (o.get("error_flags") == 0).all()
+
+
+def test_oracle_under_sanitizers():
+    """AddressSanitizer + UBSan on the CPU build of the oracle (the GPU pool has no ASan)."""
+    out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "asan-run"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("checksum") == 4 and "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr
