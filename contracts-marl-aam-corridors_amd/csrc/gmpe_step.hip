@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "gmpe_device.h"
@@ -113,7 +114,7 @@ __device__ inline Lds env_view(const Lds& l, int g, int A, int E, int D) {
 __device__ __forceinline__ bool kinematic(const gmpe_config& c) { return c.dynamics != GMPE_DYN_DOUBLE_INTEGRATOR; }
 
 __device__ __forceinline__ void vel_of(const gmpe_config& c, double a2, double a3, double& vx, double& vy) {
-    if (kinematic(c)) { vx = a3 * cos(a2); vy = a3 * sin(a2); }      // core.py:281-286
+    if (kinematic(c)) { double sn, cs; sincos(a2, &sn, &cs); vx = a3 * cs; vy = a3 * sn; }      // core.py:281-286
     else { vx = a2; vy = a3; }                                       // core.py:191-193
 }
 
@@ -478,12 +479,13 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
                     const double dt = c.dt, th0 = nv2, v0 = nv3;
                     const double th1 = th0 + u0 * dt, v1 = v0 + u1 * dt;
                     if (u0 != 0.0) {
-                        const double s0 = sin(th0), c0 = cos(th0), s1 = sin(th1), c1 = cos(th1);
+                        double s0, c0, s1, c1; sincos(th0, &s0, &c0); sincos(th1, &s1, &c1);
                         nx += (v1 * s1 - v0 * s0) / u0 + u1 * (c1 - c0) / (u0 * u0);
                         ny += (-v1 * c1 + v0 * c0) / u0 + u1 * (s1 - s0) / (u0 * u0);
                     } else {
                         const double d = (v0 + 0.5 * u1 * dt) * dt;
-                        nx += d * cos(th0); ny += d * sin(th0);
+                        double s0, c0; sincos(th0, &s0, &c0);
+                        nx += d * c0; ny += d * s0;
                     }
                     double vv = v1;
                     if (vv > c.v_max) vv = c.v_max;
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
                 }
                 if (cp == 0) rew -= norm2(v.tube[T_ENTX] - px, v.tube[T_ENTY] - py);
                 else if (cp == 1) {
-                    const double hx = cos(v.s2[i]), hy = sin(v.s2[i]);
+                    double hx, hy; sincos(v.s2[i], &hy, &hx);
                     int front = -1, back = -1; double fproj = 0, bproj = 0;
                     for (int k = 0; k < A; ++k) {                       // 1136-1143, first wins ties
                         if (k == i) continue;
@@ -993,17 +995,15 @@ static thread_local std::string g_err;
 static int fail(int code, const std::string& m) { g_err = m; return code; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(GMPE_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
+// All persistent state lives in ONE slab (256-B aligned sub-arrays): a tile's ~30 state loads then touch a
+// handful of pages instead of one page per field.
 template <typename T>
-static int dev_alloc(gmpe_handle* h, T** p, size_t n, int fill_byte) {
+static void slab_take(char* base, size_t& off, T** p, size_t n, int fill_byte, std::vector<std::pair<size_t, std::pair<size_t, int>>>& fills) {
     const size_t bytes = (n ? n : 1) * sizeof(T);
-    void* q = nullptr;
-    HIPCHK(hipMalloc(&q, bytes));
-    HIPCHK(hipMemset(q, fill_byte, bytes));
-    h->allocs.push_back(q);
-    *p = static_cast<T*>(q);
-    return GMPE_OK;
+    *p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    fills.push_back({off, {bytes, fill_byte}});
+    off = (off + bytes + 255) / 256 * 256;
 }
-
 extern "C" {
 
 int gmpe_abi_version(void) { return GMPE_ABI_VERSION; }
@@ -1070,16 +1070,32 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     h->A = cfg->num_agents; h->L = cfg->num_landmarks; h->O = cfg->num_obstacles; h->E = E; h->D = gmpe_obs_dim(cfg);
     const size_t N = cfg->num_envs, NA = N * h->A;
     DevState& s = h->s;
-    int rc = 0;
-#define AL(p, n, fill) if ((rc = dev_alloc(h, &(p), (n), (fill)))) { gmpe_destroy(h); return rc; }
-    AL(s.x, NA, 0) AL(s.y, NA, 0) AL(s.s2, NA, 0) AL(s.s3, NA, 0) AL(s.p_dist, NA, 0) AL(s.time, NA, 0)
-    AL(s.status, NA, 0) AL(s.prev_phase, NA, 0) AL(s.phase_reached, NA, 0) AL(s.cooldown, NA, 0)
-    AL(s.goal_tracker, NA, 0xFF) AL(s.current_step, N, 0) AL(s.rng_ctr, N, 0)
-    AL(s.tube, N * GMPE_TUBE_STRIDE, 0) AL(s.landmarks, N * h->L * 2, 0) AL(s.obstacles, N * h->O * 2, 0)
-    AL(s.times_required, NA, 0xFF) AL(s.dists_to_goal, NA, 0xFF) AL(s.dist_left, NA, 0xFF) AL(s.goal_reached, NA, 0xFF)
-    AL(s.n_agent_coll, NA, 0) AL(s.n_obst_coll, NA, 0) AL(s.spacing_viol, NA, 0) AL(s.steps_in_corr, NA, 0)
-    AL(s.conformance, NA, 0) AL(s.goal_min_time, NA, 0) AL(s.delta_spacing, N, 0) AL(s.error_flags, N, 0)
+    std::vector<std::pair<size_t, std::pair<size_t, int>>> fills;
+    char* slab = nullptr;
+    for (int pass = 0; pass < 2; ++pass) {                  // pass 0 sizes the slab, pass 1 hands out the pointers
+        size_t off = 0;
+        fills.clear();
+#define AL(p, n, fill) slab_take(slab, off, &(p), (n), (fill), fills);
+        AL(s.x, NA, 0) AL(s.y, NA, 0) AL(s.s2, NA, 0) AL(s.s3, NA, 0) AL(s.p_dist, NA, 0) AL(s.time, NA, 0)
+        AL(s.status, NA, 0) AL(s.prev_phase, NA, 0) AL(s.phase_reached, NA, 0) AL(s.cooldown, NA, 0)
+        AL(s.goal_tracker, NA, 0xFF) AL(s.current_step, N, 0) AL(s.rng_ctr, N, 0)
+        AL(s.tube, N * GMPE_TUBE_STRIDE, 0) AL(s.landmarks, N * h->L * 2, 0) AL(s.obstacles, N * h->O * 2, 0)
+        AL(s.times_required, NA, 0xFF) AL(s.dists_to_goal, NA, 0xFF) AL(s.dist_left, NA, 0xFF) AL(s.goal_reached, NA, 0xFF)
+        AL(s.n_agent_coll, NA, 0) AL(s.n_obst_coll, NA, 0) AL(s.spacing_viol, NA, 0) AL(s.steps_in_corr, NA, 0)
+        AL(s.conformance, NA, 0) AL(s.goal_min_time, NA, 0) AL(s.delta_spacing, N, 0) AL(s.error_flags, N, 0)
 #undef AL
+        if (pass == 0) {
+            void* q = nullptr;
+            hipError_t e = hipMalloc(&q, off);
+            if (e != hipSuccess) { gmpe_destroy(h); return fail(GMPE_ERR_HIP, std::string("hipMalloc(state slab): ") + hipGetErrorString(e)); }
+            h->allocs.push_back(q);
+            slab = static_cast<char*>(q);
+        }
+    }
+    for (auto& f : fills) {
+        hipError_t e = hipMemset(slab + f.first, f.second.second, f.second.first);
+        if (e != hipSuccess) { gmpe_destroy(h); return fail(GMPE_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e)); }
+    }
     s.tape = nullptr; s.tape_len = 0;
     // Tile shape. G envs per workgroup so that the sequential-semantics passes fill wave 0 (G*A <= 64)
     // while the per-tile LDS stays small enough for several workgroups per CU; BLOCK threads share the
