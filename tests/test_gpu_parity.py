@@ -346,3 +346,31 @@ def test_step_many_equals_host_loop():
         assert torch.equal(getattr(o1, k), getattr(o2, k)), k
     for f in ("x", "y", "s2", "s3", "rng_ctr", "current_step"):
         np.testing.assert_array_equal(e1.get(f), e2.get(f))
+
+
+@pytest.mark.parametrize("G,B", [(2, 64), (6, 128), (3, 256)])
+@pytest.mark.parametrize("scen", ["nav_metered_one_goal_graph_rotate_tube_july", "navigation_graph"])
+def test_packed_tiles_with_staggered_resets_vs_oracle(monkeypatch, G, B, scen):
+    """Several envs per workgroup, and envs of one tile resetting at DIFFERENT steps (mixed tiles):
+    the episode clocks are staggered through set_field so that resets are not simultaneous."""
+    import torch
+    monkeypatch.setenv("GMPE_G", str(G)); monkeypatch.setenv("GMPE_BLOCK", str(B))
+    N, A = 50, 10
+    cfg = gmpe.make_config(scenario_name=scen, num_envs=N, num_agents=A, num_obstacles=2 if scen == "navigation_graph" else 0,
+                           world_size=4.0, episode_length=6, seed=41)
+    eng, orc = _engine(cfg), ol.Oracle(cfg)
+    eng.reset(); orc.reset()
+    stagger = (np.arange(N) % 5).astype(np.int32)
+    eng.set("current_step", stagger); orc.set("current_step", stagger)
+    rng = np.random.RandomState(12)
+    seen_mixed = False
+    for t in range(20):
+        act = rng.randint(0, cfg.n_actions, (N, A)).astype(np.int32)
+        eo = eng.step(torch.as_tensor(act)); oo = orc.step(act)
+        _compare_step(eo, oo, cfg.num_entities, A, "G=%d t=%d" % (G, t))
+        _compare_state(eng, orc, "G=%d t=%d" % (G, t))
+        did = oo[7]
+        tiles = did[: (N // G) * G].reshape(-1, G)
+        seen_mixed |= bool(((tiles.sum(1) > 0) & (tiles.sum(1) < G)).any())
+    assert seen_mixed
+    eng.check_errors()
