@@ -343,6 +343,9 @@ __device__ __forceinline__ void static_block(const KParams& p, const Lds& l, int
 #ifndef GMPE_MIN_WAVES
 #define GMPE_MIN_WAVES 1
 #endif
+#ifndef GMPE_MIN_WAVES_NOWALLS
+#define GMPE_MIN_WAVES_NOWALLS 1
+#endif
 #ifdef GMPE_STAMPS
 #define STAMP(k) do { if (tid == 0 && p.stamps) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -354,8 +357,10 @@ __device__ __forceinline__ void static_block(const KParams& p, const Lds& l, int
 // sweep is issued before the first use (the sweeps are latency-bound: one wave per SIMD, ~100-cycle LDS reads).
 // Out-of-range iterations read a clamped index and are masked in the arithmetic. AP == 0: run-time bounds.
 #define SWEEP(var, n) _Pragma("unroll") for (int var = 0; var < (AP ? AP : (n)); ++var)
-template <int BLOCK, int AP>
-__global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) {
+// WALLS = false compiles the wall-contact code (asin / cos / softplus inside the agent lane's dynamics) out: it is
+// the single largest consumer of registers (187 -> 135 VGPRs), i.e. 2 -> 3 waves per SIMD for wall-less worlds.
+template <int BLOCK, int AP, bool WALLS>
+__global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOWALLS)) void k_env(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int A = p.A, L = p.L, O = p.O, E = p.E, D = p.D, G = p.G, N = p.c.num_envs;
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(BLOCK, GMPE_MIN_WAVES) void k_env(const KParams p) 
                     const double fx = fxg[i * C + A + o], fy = fyg[i * C + A + o];
                     if (fx != 0.0 || fy != 0.0) { sx = fx + sx; sy = fy + sy; }
                 }
-                for (int w = 0; w < c.num_walls; ++w) {
+                if (WALLS) for (int w = 0; w < c.num_walls; ++w) {
                     double wx, wy;
                     if (wall_force(c.walls[w], nx, ny, c.entity_size, c.wall_contact_force, c.wall_contact_margin, wx, wy)) { sx = sx + wx; sy = sy + wy; }
                 }
@@ -1142,10 +1147,12 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     if (lds > 160 * 1024) { gmpe_destroy(h); return fail(GMPE_ERR_UNSUPPORTED, "per-tile LDS exceeds 160 KiB"); }
     if (lds > 48 * 1024) {                                   // opt in to >64 KiB dynamic LDS (gfx950: 160 KiB per CU)
         hipError_t e = hipSuccess;
-        const void* fns[9] = {reinterpret_cast<const void*>(&k_env<64, 0>), reinterpret_cast<const void*>(&k_env<64, 3>), reinterpret_cast<const void*>(&k_env<64, 10>),
-                              reinterpret_cast<const void*>(&k_env<128, 0>), reinterpret_cast<const void*>(&k_env<128, 3>), reinterpret_cast<const void*>(&k_env<128, 10>),
-                              reinterpret_cast<const void*>(&k_env<256, 0>), reinterpret_cast<const void*>(&k_env<256, 3>), reinterpret_cast<const void*>(&k_env<256, 10>)};
-        for (int q = 0; q < 9 && e == hipSuccess; ++q) e = hipFuncSetAttribute(fns[q], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#define FN(B, P, W) reinterpret_cast<const void*>(&k_env<B, P, W>)
+        const void* fns[18] = {FN(64, 0, true), FN(64, 3, true), FN(64, 10, true), FN(128, 0, true), FN(128, 3, true), FN(128, 10, true),
+                               FN(256, 0, true), FN(256, 3, true), FN(256, 10, true), FN(64, 0, false), FN(64, 3, false), FN(64, 10, false),
+                               FN(128, 0, false), FN(128, 3, false), FN(128, 10, false), FN(256, 0, false), FN(256, 3, false), FN(256, 10, false)};
+#undef FN
+        for (int q = 0; q < 18 && e == hipSuccess; ++q) e = hipFuncSetAttribute(fns[q], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { gmpe_destroy(h); return fail(GMPE_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
     }
 #ifdef GMPE_STAMPS
@@ -1240,10 +1247,15 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
         HIPCHK(hipEventRecord(e0, st));
     }
     const int ap = (h->A == h->L && (h->A == 10 || h->A == 3)) ? h->A : 0;   // exact-size instantiations of the common cases
+    const bool walls = h->c.num_walls > 0;
+#define LAUNCH_ENV(B) do { \
+        if (walls) { if (ap == 10) hipLaunchKernelGGL((k_env<B, 10, true>), grid, dim3(B), lds, st, p); else if (ap == 3) hipLaunchKernelGGL((k_env<B, 3, true>), grid, dim3(B), lds, st, p); else hipLaunchKernelGGL((k_env<B, 0, true>), grid, dim3(B), lds, st, p); } \
+        else { if (ap == 10) hipLaunchKernelGGL((k_env<B, 10, false>), grid, dim3(B), lds, st, p); else if (ap == 3) hipLaunchKernelGGL((k_env<B, 3, false>), grid, dim3(B), lds, st, p); else hipLaunchKernelGGL((k_env<B, 0, false>), grid, dim3(B), lds, st, p); } \
+    } while (0)
     switch (h->block) {
-        case 64: if (ap == 10) hipLaunchKernelGGL((k_env<64, 10>), grid, dim3(64), lds, st, p); else if (ap == 3) hipLaunchKernelGGL((k_env<64, 3>), grid, dim3(64), lds, st, p); else hipLaunchKernelGGL((k_env<64, 0>), grid, dim3(64), lds, st, p); break;
-        case 128: if (ap == 10) hipLaunchKernelGGL((k_env<128, 10>), grid, dim3(128), lds, st, p); else if (ap == 3) hipLaunchKernelGGL((k_env<128, 3>), grid, dim3(128), lds, st, p); else hipLaunchKernelGGL((k_env<128, 0>), grid, dim3(128), lds, st, p); break;
-        default: if (ap == 10) hipLaunchKernelGGL((k_env<256, 10>), grid, dim3(256), lds, st, p); else if (ap == 3) hipLaunchKernelGGL((k_env<256, 3>), grid, dim3(256), lds, st, p); else hipLaunchKernelGGL((k_env<256, 0>), grid, dim3(256), lds, st, p); break;
+        case 64: LAUNCH_ENV(64); break;
+        case 128: LAUNCH_ENV(128); break;
+        default: LAUNCH_ENV(256); break;
     }
     HIPCHK(hipGetLastError());
     if (h->timing) { HIPCHK(hipEventRecord(e1, st)); h->ev_used += 2; }
