@@ -40,6 +40,7 @@ struct KParams {
     int mode;
     int A, L, O, E, D;
     int G;                    // envs per workgroup (G*A <= 64)
+    int spec;                 // 1: multi-wave tiles specialise (wave 0 reward/info, waves 1.. graph stores)
     int nt;                   // 1: nontemporal graph stores (outputs per launch exceed the 256 MiB Infinity Cache)
     int ablate;               // debug: timing-only builds of the kernel skip parts (GMPE_ABLATE)
     // magic multipliers for exact unsigned division by run-time constants (q < 2^22): floor(q/d) = umulhi(q, m)
@@ -340,6 +341,100 @@ __device__ __forceinline__ void static_block(const KParams& p, const Lds& l, int
     }
 }
 
+#define SWEEP(var, n) _Pragma("unroll") for (int var = 0; var < (AP ? AP : (n)); ++var)
+// Graph outputs of a tile: optional adjacency mask pass (block-wide, with its barrier), then the adj and node_obs
+// stores executed by threads t0, t0+nthr, ... (all BLOCK threads, or only the streaming waves of a specialised tile).
+template <int BLOCK, int AP>
+__device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, const int Gv, const int n0, const int tid,
+                                                const int t0, const int nthr, const bool do_mask, const int any_mask) {
+    const int A = p.A, L = p.L, E = p.E, EE = E * E, EE4 = (EE + 3) / 4 * 4;
+    const int abl = p.ablate;
+    // ---- 6. adjacency mask (…_july.py:1627-1648): rows/cols of done agents and reached landmarks -> 0.
+    // Only tiles that contain such an entity pay for this pass.
+    if (do_mask && any_mask && !(abl & 4)) {
+        for (int q = tid; q < Gv * EE; q += BLOCK) {
+            const int gg = fdiv(q, EE, p.m_EE), rc = q - gg * EE;
+            if (!l.flags[gg * 4 + 2]) continue;
+            const int r = fdiv(rc, E, p.m_E), cc = rc - r * E;
+            if (l.moff[gg * E + r] | l.moff[gg * E + cc]) l.M[(size_t)gg * EE4 + rc] = 0.0f;
+        }
+    }
+    if (do_mask) __syncthreads();
+    
+
+    // ---- 7. stream the observations out (16-byte stores wherever the row length allows)
+    if (p.o.adj && !(abl & 1)) {
+        const bool vec = (EE & 3) == 0;
+        if (p.o.adj_compact) {
+            float* dst = p.o.adj + (size_t)n0 * EE;
+            if (vec) {
+                const int nq = EE / 4;
+                for (int q = t0; q < Gv * nq; q += nthr) {
+                    const int gg = fdiv(q, nq, p.m_nq), m = q - gg * nq;
+                    if (l.flags[gg * 4 + 3]) reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(l.M + (size_t)gg * EE4)[m];
+                }
+            } else for (int q = t0; q < Gv * EE; q += nthr) { const int gg = fdiv(q, EE, p.m_EE); if (l.flags[gg * 4 + 3]) dst[q] = l.M[(size_t)gg * EE4 + (q - gg * EE)]; }
+        } else {
+            float* dst = p.o.adj + (size_t)n0 * A * EE;
+            if (vec) {
+                const int nq = EE / 4;
+                // each lane keeps one float4 of the env's matrix and stores it to the A ego copies
+                for (int q = t0; q < Gv * nq; q += nthr) {
+                    const int gg = fdiv(q, nq, p.m_nq), m = q - gg * nq;
+                    if (!l.flags[gg * 4 + 3]) continue;
+                    const float4 val = reinterpret_cast<const float4*>(l.M + (size_t)gg * EE4)[m];
+                    float4* d4 = reinterpret_cast<float4*>(dst) + (size_t)gg * A * nq + m;
+                    SWEEP(a, A) { if (!AP || a < A) { if (p.nt) nt_store4(&d4[(size_t)a * nq], val); else d4[(size_t)a * nq] = val; } }
+                }
+            } else {
+                const int AEE = A * EE;
+                for (int q = t0; q < Gv * AEE; q += nthr) {
+                    const int gg = q / AEE, rem = q - gg * AEE, rc = rem % EE;    // rare path (E*E % 4 != 0): plain division
+                    if (l.flags[gg * 4 + 3]) dst[q] = l.M[(size_t)gg * EE4 + rc];
+                }
+            }
+        }
+    }
+    
+    if (p.o.node_obs && !(abl & 2)) {
+        // node row (ego, entity k) = 2 float4: [rel_vel, rel_pos] and [rel_goal, occupied, type].
+        // A lane owns one (env, entity, half) slot, keeps that entity's data in registers and walks the egos.
+        float4* base = reinterpret_cast<float4*>(p.o.node_obs + (size_t)n0 * A * E * GMPE_NODE_FEATS);
+        const int E2 = 2 * E;
+        for (int sidx = t0; sidx < Gv * E2; sidx += nthr) {
+            const int gg = fdiv(sidx, E2, p.m_2E), rem = sidx - gg * E2;
+            if (!l.flags[gg * 4 + 3]) continue;
+            const int k = rem >> 1, half = rem & 1;
+            const int ab = gg * A, eb = gg * E;
+            const double kx = l.ex[eb + k], ky = l.ey[eb + k];
+            const bool kag = k < A;
+            const int kk = kag ? k : 0;
+            const double kvox = kag ? l.vox[ab + kk] : 0.0, kvoy = kag ? l.voy[ab + kk] : 0.0;
+            const double kvnx = kag ? l.vnx[ab + kk] : 0.0, kvny = kag ? l.vny[ab + kk] : 0.0;
+            const bool knew = kag && l.newf[ab + kk] != 0;
+            const double gx = kag ? l.ex[eb + A + kk] : kx, gy = kag ? l.ey[eb + A + kk] : ky;
+            const float occ = kag ? 0.0f : 1.0f, typ = kag ? 0.0f : (k < A + L ? 1.0f : 2.0f);
+            float4* dst = base + (size_t)gg * A * E2 + rem;
+            SWEEP(ei, A) {
+                const bool ok = !AP || ei < A;
+                const int ec = ok ? ei : 0;
+                const double px = l.ex[eb + ec], py = l.ey[eb + ec];
+                const bool en = l.newf[ab + ec] != 0;
+                const double evox = l.vox[ab + ec], evoy = l.voy[ab + ec], evnx = l.vnx[ab + ec], evny = l.vny[ab + ec];
+                float4 val;
+                if (half == 0) {
+                    const double evx = en ? evnx : evox, evy = en ? evny : evoy;
+                    const bool post = knew && k <= ec;
+                    val = make_float4((float)((post ? kvnx : kvox) - evx), (float)((post ? kvny : kvoy) - evy), (float)(kx - px), (float)(ky - py));
+                } else {
+                    val = make_float4((float)(gx - px), (float)(gy - py), occ, typ);
+                }
+                if (ok) { if (p.nt) nt_store4(&dst[(size_t)ec * E2], val); else dst[(size_t)ec * E2] = val; }
+            }
+        }
+    }
+}
+
 #ifndef GMPE_MIN_WAVES
 #define GMPE_MIN_WAVES 1
 #endif
@@ -356,7 +451,6 @@ __device__ __forceinline__ void static_block(const KParams& p, const Lds& l, int
 // AP > 0: compile-time bound (A, L <= AP) for the per-agent sweeps, so they unroll fully and every LDS read of a
 // sweep is issued before the first use (the sweeps are latency-bound: one wave per SIMD, ~100-cycle LDS reads).
 // Out-of-range iterations read a clamped index and are masked in the arithmetic. AP == 0: run-time bounds.
-#define SWEEP(var, n) _Pragma("unroll") for (int var = 0; var < (AP ? AP : (n)); ++var)
 // WALLS = false compiles the wall-contact code (asin / cos / softplus inside the agent lane's dynamics) out: it is
 // the single largest consumer of registers (187 -> 135 VGPRs), i.e. 2 -> 3 waves per SIMD for wall-less worlds.
 template <int BLOCK, int AP, bool WALLS>
@@ -599,7 +693,7 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
 
     // Sections 3+4 as one unit: in tiles without a reset they run AFTER the graph stores were issued, so the
     // reward / info arithmetic overlaps the HBM write drain.
-    auto sections34 = [&]() __attribute__((always_inline)) {
+    auto sections34 = [&](const bool block_sync) __attribute__((always_inline)) {
         // ---- 3. obs, reward, done (ego i sees agent k done iff s_old[k] || (new[k] && k < i))
         rew = 0;
         if (ag) {
@@ -699,7 +793,12 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
             v.dtg_n[i] = dtg; v.trq_n[i] = trq;
             v.sv_n[i] = sv; v.sv_o[i] = sv - (serr > 0 ? 1 : 0);
         }
-        __syncthreads();
+        if (block_sync) __syncthreads();
+        else {                                                          // every agent lane lives in wave 0: LDS ops of one wave are
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // executed in order, the fences only pin the compiler's order
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         STAMP(6);
 
         // ---- 4. info (sequential view: agents j<=i already updated, j>i not yet), outputs, write-back
@@ -759,92 +858,6 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
     for (int gg = 0; gg < Gv; ++gg) { any_reset |= l.flags[gg * 4 + 0]; any_mask |= l.flags[gg * 4 + 2]; }   // block-uniform
     const int abl = p.ablate;
 
-    auto stream_graph = [&]() __attribute__((always_inline)) {
-        // ---- 6. adjacency mask (…_july.py:1627-1648): rows/cols of done agents and reached landmarks -> 0.
-        // Only tiles that contain such an entity pay for this pass.
-        if (any_mask && !(abl & 4)) {
-            for (int q = tid; q < Gv * EE; q += BLOCK) {
-                const int gg = fdiv(q, EE, p.m_EE), rc = q - gg * EE;
-                if (!l.flags[gg * 4 + 2]) continue;
-                const int r = fdiv(rc, E, p.m_E), cc = rc - r * E;
-                if (l.moff[gg * E + r] | l.moff[gg * E + cc]) l.M[(size_t)gg * EE4 + rc] = 0.0f;
-            }
-        }
-        __syncthreads();
-        STAMP(9);
-
-        // ---- 7. stream the observations out (16-byte stores wherever the row length allows)
-        if (p.o.adj && !(abl & 1)) {
-            const bool vec = (EE & 3) == 0;
-            if (p.o.adj_compact) {
-                float* dst = p.o.adj + (size_t)n0 * EE;
-                if (vec) {
-                    const int nq = EE / 4;
-                    for (int q = tid; q < Gv * nq; q += BLOCK) {
-                        const int gg = fdiv(q, nq, p.m_nq), m = q - gg * nq;
-                        if (l.flags[gg * 4 + 3]) reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(l.M + (size_t)gg * EE4)[m];
-                    }
-                } else for (int q = tid; q < Gv * EE; q += BLOCK) { const int gg = fdiv(q, EE, p.m_EE); if (l.flags[gg * 4 + 3]) dst[q] = l.M[(size_t)gg * EE4 + (q - gg * EE)]; }
-            } else {
-                float* dst = p.o.adj + (size_t)n0 * A * EE;
-                if (vec) {
-                    const int nq = EE / 4;
-                    // each lane keeps one float4 of the env's matrix and stores it to the A ego copies
-                    for (int q = tid; q < Gv * nq; q += BLOCK) {
-                        const int gg = fdiv(q, nq, p.m_nq), m = q - gg * nq;
-                        if (!l.flags[gg * 4 + 3]) continue;
-                        const float4 val = reinterpret_cast<const float4*>(l.M + (size_t)gg * EE4)[m];
-                        float4* d4 = reinterpret_cast<float4*>(dst) + (size_t)gg * A * nq + m;
-                        SWEEP(a, A) { if (!AP || a < A) { if (p.nt) nt_store4(&d4[(size_t)a * nq], val); else d4[(size_t)a * nq] = val; } }
-                    }
-                } else {
-                    const int AEE = A * EE;
-                    for (int q = tid; q < Gv * AEE; q += BLOCK) {
-                        const int gg = q / AEE, rem = q - gg * AEE, rc = rem % EE;    // rare path (E*E % 4 != 0): plain division
-                        if (l.flags[gg * 4 + 3]) dst[q] = l.M[(size_t)gg * EE4 + rc];
-                    }
-                }
-            }
-        }
-        STAMP(10);
-        if (p.o.node_obs && !(abl & 2)) {
-            // node row (ego, entity k) = 2 float4: [rel_vel, rel_pos] and [rel_goal, occupied, type].
-            // A lane owns one (env, entity, half) slot, keeps that entity's data in registers and walks the egos.
-            float4* base = reinterpret_cast<float4*>(p.o.node_obs + (size_t)n0 * A * E * GMPE_NODE_FEATS);
-            const int E2 = 2 * E;
-            for (int sidx = tid; sidx < Gv * E2; sidx += BLOCK) {
-                const int gg = fdiv(sidx, E2, p.m_2E), rem = sidx - gg * E2;
-                if (!l.flags[gg * 4 + 3]) continue;
-                const int k = rem >> 1, half = rem & 1;
-                const int ab = gg * A, eb = gg * E;
-                const double kx = l.ex[eb + k], ky = l.ey[eb + k];
-                const bool kag = k < A;
-                const int kk = kag ? k : 0;
-                const double kvox = kag ? l.vox[ab + kk] : 0.0, kvoy = kag ? l.voy[ab + kk] : 0.0;
-                const double kvnx = kag ? l.vnx[ab + kk] : 0.0, kvny = kag ? l.vny[ab + kk] : 0.0;
-                const bool knew = kag && l.newf[ab + kk] != 0;
-                const double gx = kag ? l.ex[eb + A + kk] : kx, gy = kag ? l.ey[eb + A + kk] : ky;
-                const float occ = kag ? 0.0f : 1.0f, typ = kag ? 0.0f : (k < A + L ? 1.0f : 2.0f);
-                float4* dst = base + (size_t)gg * A * E2 + rem;
-                SWEEP(ei, A) {
-                    const bool ok = !AP || ei < A;
-                    const int ec = ok ? ei : 0;
-                    const double px = l.ex[eb + ec], py = l.ey[eb + ec];
-                    const bool en = l.newf[ab + ec] != 0;
-                    const double evox = l.vox[ab + ec], evoy = l.voy[ab + ec], evnx = l.vnx[ab + ec], evny = l.vny[ab + ec];
-                    float4 val;
-                    if (half == 0) {
-                        const double evx = en ? evnx : evox, evy = en ? evny : evoy;
-                        const bool post = knew && k <= ec;
-                        val = make_float4((float)((post ? kvnx : kvox) - evx), (float)((post ? kvny : kvoy) - evy), (float)(kx - px), (float)(ky - py));
-                    } else {
-                        val = make_float4((float)(gx - px), (float)(gy - py), occ, typ);
-                    }
-                    if (ok) { if (p.nt) nt_store4(&dst[(size_t)ec * E2], val); else dst[(size_t)ec * E2] = val; }
-                }
-            }
-        }
-    };
     auto stream_small = [&]() __attribute__((always_inline)) {
         STAMP(11);
         if (p.o.obs) {
@@ -859,8 +872,26 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
     // info arithmetic under the HBM write drain. Tiles with a reset need the terminal reward/info before the
     // reset overwrites the LDS state, so they keep the reference's order.
     const bool early = step && !any_reset;
-    if (early) stream_graph();
-    if (step) { sections34(); __syncthreads(); }
+    // Multi-wave tiles specialise: wave 0 (all agent lanes) does reward / info / write-back while waves 1.. stream the
+    // graph observations, so the ~7 us of per-agent arithmetic runs beside the store issue instead of after it.
+    const bool spec = early && BLOCK > 64 && p.spec;
+    if (early && !spec) stream_graph_fn<BLOCK, AP>(p, l, Gv, n0, tid, tid, BLOCK, true, any_mask);
+    if (spec) {
+        if (any_mask && !(abl & 4)) {
+            for (int q = tid; q < Gv * EE; q += BLOCK) {
+                const int gg = fdiv(q, EE, p.m_EE), rc = q - gg * EE;
+                if (!l.flags[gg * 4 + 2]) continue;
+                const int r = fdiv(rc, E, p.m_E), cc = rc - r * E;
+                if (l.moff[gg * E + r] | l.moff[gg * E + cc]) l.M[(size_t)gg * EE4 + rc] = 0.0f;
+            }
+        }
+        __syncthreads();
+    }
+    if (step) {
+        if (!spec || tid < 64) sections34(!spec);
+        else stream_graph_fn<BLOCK, AP>(p, l, Gv, n0, tid, tid - 64, BLOCK - 64, false, any_mask);
+        __syncthreads();
+    }
     {
         // ---- 5. reset (explicit, or the worker's auto-reset when every agent of the env is done)
         if (any_reset) {
@@ -903,7 +934,7 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
         }
         STAMP(8);
     }
-    if (!early) stream_graph();
+    if (!early) stream_graph_fn<BLOCK, AP>(p, l, Gv, n0, tid, tid, BLOCK, true, any_mask);
     stream_small();
     if (ag && err) atomicOr(&p.s.error_flags[n], err);
     STAMP(12);
@@ -999,6 +1030,7 @@ struct gmpe_handle {
     int G = 1;                       // envs per workgroup
     int ablate = 0;
     int nt = 0;
+    int spec = 0;
     unsigned long long* stamps = nullptr;
     hipEvent_t region_ev[2] = {nullptr, nullptr};
     int32_t* edge_ws = nullptr;      // [2*cap_graphs] counts | offsets
@@ -1116,9 +1148,10 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     // distance pass and the stores. GMPE_G / GMPE_BLOCK override the heuristic (tuning, tests).
     const char* env_g = getenv("GMPE_G");
     const char* env_block = getenv("GMPE_BLOCK");
-    // Heuristic (measured on MI355X, profiles/README.md): the per-agent passes are a dependent fp64 chain of
-    // ~25 us, so the kernel wants >= ~2 single-wave tiles per SIMD in flight before it packs more envs per tile.
-    int G = env_g ? atoi(env_g) : (int)(N / 2048);
+    // Heuristic (measured on MI355X, profiles/README.md): the per-agent passes are a dependent fp64 chain, so a tile packs
+    // as many envs as fit one wave (G*A <= 64) once there are enough tiles (~700) to cover the chip; multi-wave tiles
+    // specialise (wave 0: reward/info, waves 1..: graph stores). C2/C3: G = 6, BLOCK = 256 -> 683 tiles x 4 waves.
+    int G = env_g ? atoi(env_g) : (int)(N / 680);
     if (G < 1) G = 1;
     if (G > 64 / h->A) G = 64 / h->A;
     if (G < 1) G = 1;
@@ -1141,8 +1174,11 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
         h->nt = getenv("GMPE_NT") ? atoi(getenv("GMPE_NT")) : (out_bytes > 192.0 * 1024 * 1024 ? 1 : 0);
     }
     const size_t stream_f4 = (size_t)G * h->A * ((size_t)E * E / 4 + 2 * (size_t)E);
-    h->block = env_block ? atoi(env_block) : (stream_f4 <= 4096 ? 64 : (stream_f4 <= 16384 ? 128 : 256));
+    h->block = env_block ? atoi(env_block) : (stream_f4 <= 2048 ? 64 : (stream_f4 <= 6144 ? 128 : 256));
     if (h->block != 64 && h->block != 128 && h->block != 256) h->block = 256;
+    // Specialisation pays while the per-agent arithmetic is comparable to the tile's store work (C2/C3: 36.7 -> 33.4 us);
+    // store-dominated tiles (C4/C5) want every wave on the stores (C4: 1337 us vs 1421 us specialised).
+    h->spec = getenv("GMPE_SPEC") ? atoi(getenv("GMPE_SPEC")) : (stream_f4 <= 16384 ? 1 : 0);
     const size_t lds = lds_bytes(h->G, h->A, E, h->D);
     if (lds > 160 * 1024) { gmpe_destroy(h); return fail(GMPE_ERR_UNSUPPORTED, "per-tile LDS exceeds 160 KiB"); }
     if (lds > 48 * 1024) {                                   // opt in to >64 KiB dynamic LDS (gfx950: 160 KiB per CU)
@@ -1227,6 +1263,7 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
     p.A = h->A; p.L = h->L; p.O = h->O; p.E = h->E; p.D = h->D; p.G = h->G;
     p.ablate = h->ablate;
     p.nt = h->nt;
+    p.spec = h->spec;
     p.stamps = h->stamps;
     p.m_E = magic_of(p.E); p.m_AE = magic_of(p.A * p.E); p.m_EE = magic_of(p.E * p.E); p.m_nq = magic_of(p.E * p.E / 4);
     p.m_2E = magic_of(2 * p.E); p.m_pe = magic_of(p.A * p.E * 2); p.m_AD = magic_of(p.A * p.D); p.m_A = magic_of(p.A);
