@@ -113,11 +113,14 @@ __device__ inline Lds env_view(const Lds& l, int g, int A, int E, int D) {
     return v;
 }
 
-// streaming 16-byte store that does not linger in L2 (the observations are written once and read by another kernel)
+// Streaming 16-byte store with the nontemporal hint (the observations are written once and read by another kernel).
+// Written as inline asm: with the builtin inside `if (p.nt) ... else plain store` the optimiser merges the two stores and
+// drops the hint. The asm statement carries its own wait state (cdna_hip_programming.md §5.7 item 2); a store has no
+// result to wait for, and the kernel issues no load after these stores.
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void nt_store4(float4* dst, const float4& v) {
     v4f_t x = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(x, reinterpret_cast<v4f_t*>(dst));
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dst), "v"(x) : "memory");
 }
 
 __device__ __forceinline__ bool kinematic(const gmpe_config& c) { return c.dynamics != GMPE_DYN_DOUBLE_INTEGRATOR; }
@@ -691,168 +694,6 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
         STAMP(5);
     }
 
-    // Sections 3+4 as one unit: in tiles without a reset they run AFTER the graph stores were issued, so the
-    // reward / info arithmetic overlaps the HBM write drain.
-    auto sections34 = [&](const bool block_sync) __attribute__((always_inline)) {
-        // ---- 3. obs, reward, done (ego i sees agent k done iff s_old[k] || (new[k] && k < i))
-        rew = 0;
-        if (ag) {
-            const double px = v.ex[i], py = v.ey[i];
-            const double* row = v.Dm + (size_t)i * E;
-            write_obs<AP>(p, v, i, v.vox[i], v.voy[i], ph1);
-            STAMP(13);
-            // collision block (…_july.py:1117-1124) and info_callback's collision count (:780-786) in one sweep
-            int ncol_r = 0, ncol_i = 0;
-            const bool me_old = v.s_old[i] != 0, me_new = v.newf[i] != 0;
-            if (AP) {                                                  // all LDS reads of the sweep first, then the arithmetic
-                double rv[AP ? AP : 1]; int so[AP ? AP : 1], nf[AP ? AP : 1];
-#pragma unroll
-                for (int a = 0; a < AP; ++a) { const int ac = a < A ? a : 0; rv[a] = row[ac]; so[a] = v.s_old[ac]; nf[a] = v.newf[ac]; }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int a = 0; a < AP; ++a) {
-                    const bool close = a < A && rv[a] < c.sep_dist && a != i;
-                    ncol_r += (close && !so[a] && !(nf[a] && a < i)) ? 1 : 0;
-                    ncol_i += (close && !so[a] && !(nf[a] && a <= i)) ? 1 : 0;
-                }
-            } else {
-                for (int a = 0; a < A; ++a) {
-                    const bool close = row[a] < c.sep_dist && a != i;
-                    const int so = v.s_old[a], nf = v.newf[a];
-                    ncol_r += (close && !so && !(nf && a < i)) ? 1 : 0;
-                    ncol_i += (close && !so && !(nf && a <= i)) ? 1 : 0;
-                }
-            }
-            if (me_old) { ncol_r = 0; }
-            if (me_old || me_new) ncol_i = 0;
-            for (int q = 0; q < ncol_r; ++q) rew -= c.collision_rew * 4;
-            nac += ncol_i;
-            STAMP(14);
-            const bool obst_hit = obstacle_collision_ego(p, v, i);
-            if (obst_hit) { rew -= c.collision_rew * 3; noc += 1; }
-            double serr = 0;
-            if (july) {
-                const double tdx = v.tube[T_EXX] - v.tube[T_ENTX], tdy = v.tube[T_EXY] - v.tube[T_ENTY];
-                const double tlen = sqrt(tdx * tdx + tdy * tdy);
-                if (cp == 2 && cp > prevA + 1) rew -= c.goal_rew * 3;
-                const double ux = tdx / tlen, uy = tdy / tlen;
-                const double qx = px - v.tube[T_ENTX], qy = py - v.tube[T_ENTY];
-                const double proj = qx * ux + qy * uy;
-                if (cp == prevA + 1 && phase_reached == cp - 1) {
-                    if (cp == 1) {
-                        const double edist = norm2(qx - proj * tdx, qy - proj * tdy);   // un-normalised (:1154)
-                        if (0 <= proj && proj < 0.1 * tlen && edist < 0.2 * tlen) rew += c.goal_rew * 3;
-                    } else if (cp == 2) rew += c.goal_rew * 3;
-                }
-                if (cp == 0) rew -= norm2(v.tube[T_ENTX] - px, v.tube[T_ENTY] - py);
-                else if (cp == 1) {
-                    double hx, hy; sincos(v.s2[i], &hy, &hx);
-                    int front = -1, back = -1; double fproj = 0, bproj = 0;
-                    for (int k = 0; k < A; ++k) {                       // 1136-1143, first wins ties
-                        if (k == i) continue;
-                        const double pj = (v.ex[k] - px) * hx + (v.ey[k] - py) * hy;
-                        if (pj > 0) { if (front < 0 || pj < fproj) { front = k; fproj = pj; } }
-                        else { if (back < 0 || pj > bproj) { back = k; bproj = pj; } }
-                    }
-                    if (front >= 0) { const double df = row[front] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
-                    if (back >= 0) { const double df = row[back] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
-                    if (serr > 0) sv += 1;
-                    rew -= serr * c.formation_rew;
-                    rew -= norm2(v.tube[T_EXX] - px, v.tube[T_EXY] - py);
-                    sic += 1;
-                } else if (cp == 2 && phase_reached == 0) cp = 0;
-                else {
-                    if (dgoal < c.goal_thresh) { if (me_new) rew += c.goal_rew * 5; }
-                    else rew -= dgoal;
-                }
-                if (phase_reached == 1 && cp == 0) conf += 1;
-                if (cp > phase_reached) phase_reached = cp;
-                if (cp < prevA) rew -= c.collision_rew * 3;
-                if (cp < phase_reached) rew -= c.collision_rew;
-                prev_phase = cp;
-            } else {
-                if (dgoal < c.goal_thresh) { if (me_new) rew += c.goal_rew * 5; }
-                else rew -= dgoal;
-            }
-            rew = clipd(rew, -4 * c.collision_rew, c.goal_rew * 5);
-            rew = clipd(rew, c.min_reward, c.max_reward);
-            v.serr[i] = serr; v.rew[i] = rew;
-
-            STAMP(15);
-            // ---- info counters that depend on own data only (…_july.py:744-773)
-            v.dtg_o[i] = dtg; v.trq_o[i] = trq;
-            int nearest = 0; double dmin = INF;
-            SWEEP(q, L) { const bool ok = !AP || q < L; const double d = ok ? row[A + (ok ? q : 0)] : INF; const bool lt = d < dmin; dmin = lt ? d : dmin; nearest = lt ? q : nearest; }
-            const double thr = c.goal_thresh;
-            const int tnow = (int)((double)cur_step * c.dt);
-            if (dmin < thr && (nearest != greached && greached != -1)) { greached = nearest; dleft = (int)dmin; }
-            if (dmin < thr && trq == -1) { trq = tnow; dtg = (int)p_dist; dleft = (int)dmin; greached = nearest; }
-            if (trq == -1) { dtg = (int)p_dist; dleft = (int)dmin; }
-            if (dmin > thr && trq != -1) { dtg = (int)p_dist; trq = tnow; dleft = (int)dmin; }
-            if (dmin < thr && nearest == greached) { dleft = (int)dmin; greached = nearest; }
-            v.dtg_n[i] = dtg; v.trq_n[i] = trq;
-            v.sv_n[i] = sv; v.sv_o[i] = sv - (serr > 0 ? 1 : 0);
-        }
-        if (block_sync) __syncthreads();
-        else {                                                          // every agent lane lives in wave 0: LDS ops of one wave are
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // executed in order, the fences only pin the compiler's order
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        STAMP(6);
-
-        // ---- 4. info (sequential view: agents j<=i already updated, j>i not yet), outputs, write-back
-        if (ag) {
-            double rsum = 0;
-            if (c.collaborative) for (int a = 0; a < A; ++a) rsum += v.rew[a];
-            if (p.o.reward) p.o.reward[na] = (float)(c.collaborative ? rsum : rew);
-            if (p.o.done) p.o.done[na] = done ? 1 : 0;
-            if (p.o.info) {
-                // the counters are small integers: their sums and sums of squares are exact in fp64 in any order
-                double sd = 0, st = 0, sdd = 0, stt = 0; int ssv = 0;
-                SWEEP(a, A) {
-                    const bool ok = !AP || a < A;
-                    const int ac = ok ? a : 0;
-                    const bool nw = ac <= i;
-                    const int dn = v.dtg_n[ac], d_o = v.dtg_o[ac], tn = v.trq_n[ac], to = v.trq_o[ac], svn = v.sv_n[ac], svo = v.sv_o[ac];
-                    const double dd = ok ? (double)(nw ? dn : d_o) : 0.0, tt = ok ? (double)(nw ? tn : to) : 0.0;
-                    sd += dd; st += tt; sdd += dd * dd; stt += tt * tt;
-                    ssv += ok ? (nw ? svn : svo) : 0;
-                }
-                double dsp = dsp0;
-                if (july) for (int a = 0; a <= i; ++a) dsp += v.serr[a];   // same order as the list append (:1180)
-                const double dm = sd / A, tm = st / A;
-                // population variance = (A*sum(x^2) - sum(x)^2) / A^2, numerator exact
-                const double dvn = (double)A * sdd - sd * sd, tvn = (double)A * stt - st * st;
-                const double ds = sqrt(dvn) / A, ts = sqrt(tvn) / A;
-                float* o = p.o.info + na * GMPE_INFO_KEYS;
-                o[0] = (float)rew; o[1] = (float)dleft; o[2] = (float)trq; o[3] = (float)nac; o[4] = (float)noc;
-                o[5] = (float)dm; o[6] = (float)ds; o[7] = (float)(dm / (ds + 0.0001)); o[8] = (float)dtg;
-                o[9] = (float)trq; o[10] = (float)tm; o[11] = (float)ts; o[12] = (float)(tm / (ts + 0.0001));
-                o[13] = (float)((double)conf / c.episode_length);
-                o[14] = (float)(dsp / (ssv != 0 ? (double)ssv : 1.0));
-                o[15] = (float)((double)sv / (sic != 0 ? sic : 1));
-                o[16] = (float)gmt;
-            }
-            if (!all_done) {                                            // persist the stepped state
-                if (i == 0) {
-                    double dsp = dsp0;
-                    if (july) for (int a = 0; a < A; ++a) dsp += v.serr[a];
-                    p.s.delta_spacing[n] = dsp;
-                    p.s.rng_ctr[n] = ctr0 + v.flags[1];
-                    p.s.current_step[n] = cur_step;
-                }
-                p.s.x[na] = v.ex[i]; p.s.y[na] = v.ey[i]; p.s.s2[na] = v.n2[i]; p.s.s3[na] = v.n3[i];
-                p.s.status[na] = (uint8_t)(v.s_old[i] || v.newf[i]);
-                p.s.prev_phase[na] = prev_phase; p.s.phase_reached[na] = phase_reached; p.s.cooldown[na] = cooldown;
-                p.s.goal_tracker[na] = v.gt[i]; p.s.p_dist[na] = p_dist; p.s.time[na] = tim;
-                p.s.times_required[na] = trq; p.s.dists_to_goal[na] = dtg; p.s.dist_left[na] = dleft;
-                p.s.goal_reached[na] = greached; p.s.n_agent_coll[na] = nac; p.s.n_obst_coll[na] = noc;
-                p.s.spacing_viol[na] = sv; p.s.steps_in_corr[na] = sic; p.s.conformance[na] = conf;
-            }
-        }
-        STAMP(7);
-    };
 
     int any_reset = 0, any_mask = 0;
     for (int gg = 0; gg < Gv; ++gg) { any_reset |= l.flags[gg * 4 + 0]; any_mask |= l.flags[gg * 4 + 2]; }   // block-uniform
@@ -888,7 +729,169 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
         __syncthreads();
     }
     if (step) {
-        if (!spec || tid < 64) sections34(!spec);
+        if (!spec || tid < 64) {
+            // ---- sections 3+4 (obs, reward, info, write-back). In specialised tiles only wave 0 gets here and the
+            // block barrier between the two sections is replaced by wave-local ordering.
+            const bool block_sync = !spec;
+            // ---- 3. obs, reward, done (ego i sees agent k done iff s_old[k] || (new[k] && k < i))
+            rew = 0;
+            if (ag) {
+                const double px = v.ex[i], py = v.ey[i];
+                const double* row = v.Dm + (size_t)i * E;
+                write_obs<AP>(p, v, i, v.vox[i], v.voy[i], ph1);
+                STAMP(13);
+                // collision block (…_july.py:1117-1124) and info_callback's collision count (:780-786) in one sweep
+                int ncol_r = 0, ncol_i = 0;
+                const bool me_old = v.s_old[i] != 0, me_new = v.newf[i] != 0;
+                if (AP) {                                                  // all LDS reads of the sweep first, then the arithmetic
+                    double rv[AP ? AP : 1]; int so[AP ? AP : 1], nf[AP ? AP : 1];
+    #pragma unroll
+                    for (int a = 0; a < AP; ++a) { const int ac = a < A ? a : 0; rv[a] = row[ac]; so[a] = v.s_old[ac]; nf[a] = v.newf[ac]; }
+                    __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                    for (int a = 0; a < AP; ++a) {
+                        const bool close = a < A && rv[a] < c.sep_dist && a != i;
+                        ncol_r += (close && !so[a] && !(nf[a] && a < i)) ? 1 : 0;
+                        ncol_i += (close && !so[a] && !(nf[a] && a <= i)) ? 1 : 0;
+                    }
+                } else {
+                    for (int a = 0; a < A; ++a) {
+                        const bool close = row[a] < c.sep_dist && a != i;
+                        const int so = v.s_old[a], nf = v.newf[a];
+                        ncol_r += (close && !so && !(nf && a < i)) ? 1 : 0;
+                        ncol_i += (close && !so && !(nf && a <= i)) ? 1 : 0;
+                    }
+                }
+                if (me_old) { ncol_r = 0; }
+                if (me_old || me_new) ncol_i = 0;
+                for (int q = 0; q < ncol_r; ++q) rew -= c.collision_rew * 4;
+                nac += ncol_i;
+                STAMP(14);
+                const bool obst_hit = obstacle_collision_ego(p, v, i);
+                if (obst_hit) { rew -= c.collision_rew * 3; noc += 1; }
+                double serr = 0;
+                if (july) {
+                    const double tdx = v.tube[T_EXX] - v.tube[T_ENTX], tdy = v.tube[T_EXY] - v.tube[T_ENTY];
+                    const double tlen = sqrt(tdx * tdx + tdy * tdy);
+                    if (cp == 2 && cp > prevA + 1) rew -= c.goal_rew * 3;
+                    const double ux = tdx / tlen, uy = tdy / tlen;
+                    const double qx = px - v.tube[T_ENTX], qy = py - v.tube[T_ENTY];
+                    const double proj = qx * ux + qy * uy;
+                    if (cp == prevA + 1 && phase_reached == cp - 1) {
+                        if (cp == 1) {
+                            const double edist = norm2(qx - proj * tdx, qy - proj * tdy);   // un-normalised (:1154)
+                            if (0 <= proj && proj < 0.1 * tlen && edist < 0.2 * tlen) rew += c.goal_rew * 3;
+                        } else if (cp == 2) rew += c.goal_rew * 3;
+                    }
+                    if (cp == 0) rew -= norm2(v.tube[T_ENTX] - px, v.tube[T_ENTY] - py);
+                    else if (cp == 1) {
+                        double hx, hy; sincos(v.s2[i], &hy, &hx);
+                        int front = -1, back = -1; double fproj = 0, bproj = 0;
+                        for (int k = 0; k < A; ++k) {                       // 1136-1143, first wins ties
+                            if (k == i) continue;
+                            const double pj = (v.ex[k] - px) * hx + (v.ey[k] - py) * hy;
+                            if (pj > 0) { if (front < 0 || pj < fproj) { front = k; fproj = pj; } }
+                            else { if (back < 0 || pj > bproj) { back = k; bproj = pj; } }
+                        }
+                        if (front >= 0) { const double df = row[front] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
+                        if (back >= 0) { const double df = row[back] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
+                        if (serr > 0) sv += 1;
+                        rew -= serr * c.formation_rew;
+                        rew -= norm2(v.tube[T_EXX] - px, v.tube[T_EXY] - py);
+                        sic += 1;
+                    } else if (cp == 2 && phase_reached == 0) cp = 0;
+                    else {
+                        if (dgoal < c.goal_thresh) { if (me_new) rew += c.goal_rew * 5; }
+                        else rew -= dgoal;
+                    }
+                    if (phase_reached == 1 && cp == 0) conf += 1;
+                    if (cp > phase_reached) phase_reached = cp;
+                    if (cp < prevA) rew -= c.collision_rew * 3;
+                    if (cp < phase_reached) rew -= c.collision_rew;
+                    prev_phase = cp;
+                } else {
+                    if (dgoal < c.goal_thresh) { if (me_new) rew += c.goal_rew * 5; }
+                    else rew -= dgoal;
+                }
+                rew = clipd(rew, -4 * c.collision_rew, c.goal_rew * 5);
+                rew = clipd(rew, c.min_reward, c.max_reward);
+                v.serr[i] = serr; v.rew[i] = rew;
+
+                STAMP(15);
+                // ---- info counters that depend on own data only (…_july.py:744-773)
+                v.dtg_o[i] = dtg; v.trq_o[i] = trq;
+                int nearest = 0; double dmin = INF;
+                SWEEP(q, L) { const bool ok = !AP || q < L; const double d = ok ? row[A + (ok ? q : 0)] : INF; const bool lt = d < dmin; dmin = lt ? d : dmin; nearest = lt ? q : nearest; }
+                const double thr = c.goal_thresh;
+                const int tnow = (int)((double)cur_step * c.dt);
+                if (dmin < thr && (nearest != greached && greached != -1)) { greached = nearest; dleft = (int)dmin; }
+                if (dmin < thr && trq == -1) { trq = tnow; dtg = (int)p_dist; dleft = (int)dmin; greached = nearest; }
+                if (trq == -1) { dtg = (int)p_dist; dleft = (int)dmin; }
+                if (dmin > thr && trq != -1) { dtg = (int)p_dist; trq = tnow; dleft = (int)dmin; }
+                if (dmin < thr && nearest == greached) { dleft = (int)dmin; greached = nearest; }
+                v.dtg_n[i] = dtg; v.trq_n[i] = trq;
+                v.sv_n[i] = sv; v.sv_o[i] = sv - (serr > 0 ? 1 : 0);
+            }
+            if (block_sync) __syncthreads();
+            else {                                                          // every agent lane lives in wave 0: LDS ops of one wave are
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // executed in order, the fences only pin the compiler's order
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            STAMP(6);
+
+            // ---- 4. info (sequential view: agents j<=i already updated, j>i not yet), outputs, write-back
+            if (ag) {
+                double rsum = 0;
+                if (c.collaborative) for (int a = 0; a < A; ++a) rsum += v.rew[a];
+                if (p.o.reward) p.o.reward[na] = (float)(c.collaborative ? rsum : rew);
+                if (p.o.done) p.o.done[na] = done ? 1 : 0;
+                if (p.o.info) {
+                    // the counters are small integers: their sums and sums of squares are exact in fp64 in any order
+                    double sd = 0, st = 0, sdd = 0, stt = 0; int ssv = 0;
+                    SWEEP(a, A) {
+                        const bool ok = !AP || a < A;
+                        const int ac = ok ? a : 0;
+                        const bool nw = ac <= i;
+                        const int dn = v.dtg_n[ac], d_o = v.dtg_o[ac], tn = v.trq_n[ac], to = v.trq_o[ac], svn = v.sv_n[ac], svo = v.sv_o[ac];
+                        const double dd = ok ? (double)(nw ? dn : d_o) : 0.0, tt = ok ? (double)(nw ? tn : to) : 0.0;
+                        sd += dd; st += tt; sdd += dd * dd; stt += tt * tt;
+                        ssv += ok ? (nw ? svn : svo) : 0;
+                    }
+                    double dsp = dsp0;
+                    if (july) for (int a = 0; a <= i; ++a) dsp += v.serr[a];   // same order as the list append (:1180)
+                    const double dm = sd / A, tm = st / A;
+                    // population variance = (A*sum(x^2) - sum(x)^2) / A^2, numerator exact
+                    const double dvn = (double)A * sdd - sd * sd, tvn = (double)A * stt - st * st;
+                    const double ds = sqrt(dvn) / A, ts = sqrt(tvn) / A;
+                    float* o = p.o.info + na * GMPE_INFO_KEYS;
+                    o[0] = (float)rew; o[1] = (float)dleft; o[2] = (float)trq; o[3] = (float)nac; o[4] = (float)noc;
+                    o[5] = (float)dm; o[6] = (float)ds; o[7] = (float)(dm / (ds + 0.0001)); o[8] = (float)dtg;
+                    o[9] = (float)trq; o[10] = (float)tm; o[11] = (float)ts; o[12] = (float)(tm / (ts + 0.0001));
+                    o[13] = (float)((double)conf / c.episode_length);
+                    o[14] = (float)(dsp / (ssv != 0 ? (double)ssv : 1.0));
+                    o[15] = (float)((double)sv / (sic != 0 ? sic : 1));
+                    o[16] = (float)gmt;
+                }
+                if (!all_done) {                                            // persist the stepped state
+                    if (i == 0) {
+                        double dsp = dsp0;
+                        if (july) for (int a = 0; a < A; ++a) dsp += v.serr[a];
+                        p.s.delta_spacing[n] = dsp;
+                        p.s.rng_ctr[n] = ctr0 + v.flags[1];
+                        p.s.current_step[n] = cur_step;
+                    }
+                    p.s.x[na] = v.ex[i]; p.s.y[na] = v.ey[i]; p.s.s2[na] = v.n2[i]; p.s.s3[na] = v.n3[i];
+                    p.s.status[na] = (uint8_t)(v.s_old[i] || v.newf[i]);
+                    p.s.prev_phase[na] = prev_phase; p.s.phase_reached[na] = phase_reached; p.s.cooldown[na] = cooldown;
+                    p.s.goal_tracker[na] = v.gt[i]; p.s.p_dist[na] = p_dist; p.s.time[na] = tim;
+                    p.s.times_required[na] = trq; p.s.dists_to_goal[na] = dtg; p.s.dist_left[na] = dleft;
+                    p.s.goal_reached[na] = greached; p.s.n_agent_coll[na] = nac; p.s.n_obst_coll[na] = noc;
+                    p.s.spacing_viol[na] = sv; p.s.steps_in_corr[na] = sic; p.s.conformance[na] = conf;
+                }
+            }
+            STAMP(7);
+        }
         else stream_graph_fn<BLOCK, AP>(p, l, Gv, n0, tid, tid - 64, BLOCK - 64, false, any_mask);
         __syncthreads();
     }

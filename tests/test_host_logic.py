@@ -257,3 +257,15 @@ def test_oracle_under_sanitizers():
     out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "asan-run"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("checksum") == 4 and "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr
+
+
+def test_kernels_do_not_spill():
+    """Every instantiation of the fused kernel must fit the register file (a spill costs 3x on this kernel:
+    the inlined per-agent code is large and a non-inlined closure silently moves its state to scratch)."""
+    out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "contracts-marl-aam-corridors_amd", "csrc"), "resource-usage"],
+                         capture_output=True, text=True, timeout=600)
+    txt = out.stdout + out.stderr
+    names = re.findall(r"Function Name: (\S*k_env\S*)", txt)
+    scratch = re.findall(r"Function Name: \S*k_env\S*.*?ScratchSize \[bytes/lane\]: (\d+)", txt, flags=re.S)
+    assert len(names) >= 18 and len(scratch) == len(names)
+    assert all(int(x) == 0 for x in scratch), list(zip(names, scratch))
