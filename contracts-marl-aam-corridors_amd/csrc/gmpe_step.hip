@@ -141,14 +141,14 @@ __device__ __forceinline__ bool wall_band_hit(const KParams& p, double px, doubl
     return false;
 }
 // Scenario.is_obstacle_collision (…_july.py:864-890) at an arbitrary point (reset placement)
-__device__ inline bool obstacle_collision(const KParams& p, const Lds& l, double px, double py, double size) {
+__device__ __forceinline__ bool obstacle_collision(const KParams& p, const Lds& l, double px, double py, double size) {
     const int o0 = p.A + p.L;
     for (int o = 0; o < p.O; ++o)
         if (norm2(l.ex[o0 + o] - px, l.ey[o0 + o] - py) < 2.0 * (p.c.entity_size + size)) return true;
     return wall_band_hit(p, px, py, size);
 }
 // same test for agent i at its current position, distances taken from the shared fp64 rows
-__device__ inline bool obstacle_collision_ego(const KParams& p, const Lds& l, int i) {
+__device__ __forceinline__ bool obstacle_collision_ego(const KParams& p, const Lds& l, int i) {
     const double* row = l.Dm + (size_t)i * p.E + p.A + p.L;
     for (int o = 0; o < p.O; ++o)
         if (row[o] < 2.0 * (p.c.entity_size + p.c.entity_size)) return true;
@@ -156,7 +156,7 @@ __device__ inline bool obstacle_collision_ego(const KParams& p, const Lds& l, in
 }
 
 // _set_action (environment.py:336-475)
-__device__ inline void decode_action(const gmpe_config& c, int idx, double& u0, double& u1) {
+__device__ __forceinline__ void decode_action(const gmpe_config& c, int idx, double& u0, double& u1) {
     if (c.dynamics == GMPE_DYN_DOUBLE_INTEGRATOR) {
         if (c.n_actions == 5) {
             u0 = (idx == 1 ? 1.0 : 0.0) - (idx == 2 ? 1.0 : 0.0);
@@ -219,7 +219,7 @@ __device__ __forceinline__ void write_obs(const KParams& p, const Lds& l, int i,
 // Serial reset of one env by ONE lane (reset_world: …_july.py:339-420, 440-515, 518-613,
 // custom_scenarios/utils.py:165-193; navigation_graph: DESIGN.md). Writes positions / headings to
 // LDS (ex, ey, n2, n3, tube) and landmark / obstacle / tube records to HBM. Bounded rejection loop.
-__device__ void reset_world_serial(const KParams& p, const Lds& l, int n, int64_t& ctr, int& err) {
+__device__ __forceinline__ void reset_world_serial(const KParams& p, const Lds& l, int n, int64_t& ctr, int& err) {
     const gmpe_config& c = p.c;
     const double ws = c.world_size, size = c.entity_size;
     const int A = p.A, L = p.L, O = p.O;
@@ -699,15 +699,6 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
     for (int gg = 0; gg < Gv; ++gg) { any_reset |= l.flags[gg * 4 + 0]; any_mask |= l.flags[gg * 4 + 2]; }   // block-uniform
     const int abl = p.ablate;
 
-    auto stream_small = [&]() __attribute__((always_inline)) {
-        STAMP(11);
-        if (p.o.obs) {
-            float* dst = p.o.obs + (size_t)n0 * A * D;
-            const int AD = A * D;
-            for (int q = tid; q < Gv * AD; q += BLOCK) { const int gg = fdiv(q, AD, p.m_AD); if (l.flags[gg * 4 + 3]) dst[q] = l.obs[(size_t)gg * AD4 + (q - gg * AD)]; }
-        }
-        if (p.o.agent_id) for (int q = tid; q < Gv * A; q += BLOCK) { const int gg = fdiv(q, A, p.m_A); if (l.flags[gg * 4 + 3]) p.o.agent_id[(size_t)n0 * A + q] = q - gg * A; }   // get_id :1554
-    };
 
     // Common case (no env of the tile resets): issue the 22 KB/env of graph stores FIRST, then do the reward /
     // info arithmetic under the HBM write drain. Tiles with a reset need the terminal reward/info before the
@@ -938,7 +929,14 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
         STAMP(8);
     }
     if (!early) stream_graph_fn<BLOCK, AP>(p, l, Gv, n0, tid, tid, BLOCK, true, any_mask);
-    stream_small();
+    // ---- small outputs: obs staging rows and agent ids
+    STAMP(11);
+    if (p.o.obs) {
+        float* dst = p.o.obs + (size_t)n0 * A * D;
+        const int AD = A * D;
+        for (int q = tid; q < Gv * AD; q += BLOCK) { const int gg = fdiv(q, AD, p.m_AD); if (l.flags[gg * 4 + 3]) dst[q] = l.obs[(size_t)gg * AD4 + (q - gg * AD)]; }
+    }
+    if (p.o.agent_id) for (int q = tid; q < Gv * A; q += BLOCK) { const int gg = fdiv(q, A, p.m_A); if (l.flags[gg * 4 + 3]) p.o.agent_id[(size_t)n0 * A + q] = q - gg * A; }   // get_id :1554
     if (ag && err) atomicOr(&p.s.error_flags[n], err);
     STAMP(12);
 }
