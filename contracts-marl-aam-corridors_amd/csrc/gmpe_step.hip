@@ -311,19 +311,34 @@ template <int BLOCK>
 __device__ __forceinline__ void distance_pass(const KParams& p, const Lds& l, int G, int tid, bool only_reset) {
     const int A = p.A, E = p.E, AE = A * E, EE4 = (E * E + 3) / 4 * 4;
     const int NP = A * (A - 1) / 2, S = E - A, AS = A * S, W = NP + AS;   // per env: agent pairs + agent x static entities
-    for (int q = tid; q < G * W; q += BLOCK) {
-        const int g = fdiv(q, W, p.m_W), w = q - g * W;
-        if (only_reset && !l.flags[g * 4 + 0]) continue;
-        int r, cc;
-        if (w < NP) { const int pk = l.ptab[w]; r = pk >> 8; cc = pk & 255; }
-        else { const int t = w - NP; r = fdiv(t, S, p.m_Sx); cc = A + (t - r * S); }
-        const double dx = l.ex[g * E + r] - l.ex[g * E + cc], dy = l.ey[g * E + r] - l.ey[g * E + cc];   // r < cc always
-        const double d = sqrt(dx * dx + dy * dy);
-        double* Dg = l.Dm + (size_t)g * AE;
-        float* Mg = l.M + (size_t)g * EE4;
-        const float df = (float)d;
-        Dg[r * E + cc] = d; Mg[r * E + cc] = df; Mg[cc * E + r] = df;
-        if (cc < A) Dg[cc * E + r] = d;
+    const int total = G * W;
+    for (int q0 = tid; q0 < total; q0 += 2 * BLOCK) {                   // two independent entries per trip
+        double ds[2]; int gs[2], rs[2], cs[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = q0 + u * BLOCK;
+            const bool live = q < total;
+            const int qq = live ? q : tid;
+            const int g = fdiv(qq, W, p.m_W), w = qq - g * W;
+            const bool ap_ = w < NP;
+            const int pk = l.ptab[ap_ ? w : 0];
+            const int t = ap_ ? 0 : w - NP;
+            const int ro = fdiv(t, S, p.m_Sx);
+            const int r = ap_ ? (pk >> 8) : ro, cc = ap_ ? (pk & 255) : A + (t - ro * S);   // r < cc always
+            const double dx = l.ex[g * E + r] - l.ex[g * E + cc], dy = l.ey[g * E + r] - l.ey[g * E + cc];
+            ds[u] = sqrt(dx * dx + dy * dy);
+            gs[u] = (live && !(only_reset && !l.flags[g * 4 + 0])) ? g : -1; rs[u] = r; cs[u] = cc;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (gs[u] < 0) continue;
+            const int r = rs[u], cc = cs[u];
+            double* Dg = l.Dm + (size_t)gs[u] * AE;
+            float* Mg = l.M + (size_t)gs[u] * EE4;
+            const float df = (float)ds[u];
+            Dg[r * E + cc] = ds[u]; Mg[r * E + cc] = df; Mg[cc * E + r] = df;
+            if (cc < A) Dg[cc * E + r] = ds[u];
+        }
     }
     for (int q = tid; q < G * A; q += BLOCK) {                           // diagonal
         const int g = fdiv(q, A, p.m_A), r = q - g * A;
@@ -882,6 +897,17 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
                 }
             }
             STAMP(7);
+            if (spec) {                                                 // wave-local: the rows were written by this wave's own lanes
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (p.o.obs) {
+                    float* dst = p.o.obs + (size_t)n0 * A * D;
+                    const int AD = A * D;
+                    for (int q = tid; q < Gv * AD; q += 64) { const int gg = fdiv(q, AD, p.m_AD); if (l.flags[gg * 4 + 3]) dst[q] = l.obs[(size_t)gg * AD4 + (q - gg * AD)]; }
+                }
+                if (p.o.agent_id) for (int q = tid; q < Gv * A; q += 64) { const int gg = fdiv(q, A, p.m_A); if (l.flags[gg * 4 + 3]) p.o.agent_id[(size_t)n0 * A + q] = q - gg * A; }
+            }
         }
         else stream_graph_fn<BLOCK, AP>(p, l, Gv, n0, tid, tid - 64, BLOCK - 64, false, any_mask);
         __syncthreads();
@@ -929,14 +955,17 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
         STAMP(8);
     }
     if (!early) stream_graph_fn<BLOCK, AP>(p, l, Gv, n0, tid, tid, BLOCK, true, any_mask);
-    // ---- small outputs: obs staging rows and agent ids
+    // ---- small outputs: obs staging rows and agent ids. In a specialised tile wave 0 has already stored them
+    // (it wrote the staging rows itself), so nobody waits behind the barrier for the streaming waves.
     STAMP(11);
-    if (p.o.obs) {
-        float* dst = p.o.obs + (size_t)n0 * A * D;
-        const int AD = A * D;
-        for (int q = tid; q < Gv * AD; q += BLOCK) { const int gg = fdiv(q, AD, p.m_AD); if (l.flags[gg * 4 + 3]) dst[q] = l.obs[(size_t)gg * AD4 + (q - gg * AD)]; }
+    if (!spec) {
+        if (p.o.obs) {
+            float* dst = p.o.obs + (size_t)n0 * A * D;
+            const int AD = A * D;
+            for (int q = tid; q < Gv * AD; q += BLOCK) { const int gg = fdiv(q, AD, p.m_AD); if (l.flags[gg * 4 + 3]) dst[q] = l.obs[(size_t)gg * AD4 + (q - gg * AD)]; }
+        }
+        if (p.o.agent_id) for (int q = tid; q < Gv * A; q += BLOCK) { const int gg = fdiv(q, A, p.m_A); if (l.flags[gg * 4 + 3]) p.o.agent_id[(size_t)n0 * A + q] = q - gg * A; }   // get_id :1554
     }
-    if (p.o.agent_id) for (int q = tid; q < Gv * A; q += BLOCK) { const int gg = fdiv(q, A, p.m_A); if (l.flags[gg * 4 + 3]) p.o.agent_id[(size_t)n0 * A + q] = q - gg * A; }   // get_id :1554
     if (ag && err) atomicOr(&p.s.error_flags[n], err);
     STAMP(12);
 }
