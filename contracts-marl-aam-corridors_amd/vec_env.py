@@ -64,7 +64,7 @@ class BatchedGraphMPEVecEnv(object):
     viewer = None
     metadata = {"render.modes": ["human", "rgb_array"]}
 
-    def __init__(self, all_args, num_envs=None, device=0, env_id_base=0, adj_broadcast_view=True):
+    def __init__(self, all_args, num_envs=None, device=0, env_id_base=0, adj_broadcast_view=True, pinned_host=True):
         self.cfg = config_from_args(all_args, num_envs=num_envs, env_id_base=env_id_base)
         # The reference's per-agent adj arrays alias ONE E x E matrix per env, so the
         # engine writes that matrix once and the [N,A,E,E] result is a zero-copy broadcast view.
@@ -86,24 +86,45 @@ class BatchedGraphMPEVecEnv(object):
         self.share_agent_id_observation_space = [Box(-np.inf, np.inf, (A * 1,), f32) for _ in range(A)]
         self.waiting = False
         self._pending = None
+        # Host hand-off for the NumPy runner: two alternating sets of pinned staging buffers, filled by asynchronous
+        # D2H copies on the engine's stream (arrays returned by step t stay valid until step t+2; the runner copies
+        # them into its replay buffer immediately, graph_buffer.py:223-236). pinned_host=False returns fresh arrays.
+        self._pinned = bool(pinned_host)
+        self._host = None
+        self._flip = 0
+        if self._pinned:
+            o = self.engine.out
+            mk = lambda t: torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
+            self._host = [dict(obs=mk(o.obs), agent_id=mk(o.agent_id), node_obs=mk(o.node_obs), adj=mk(o.adj),
+                               reward=mk(o.reward), done=mk(o.done)) for _ in range(2)]
 
     # ------------------------------------------------------------------ helpers
-    def _adj_np(self, adj):
-        a = adj.detach().cpu().numpy()
+    def _expand_adj(self, a):
         if self._compact:
             N, E = a.shape[0], a.shape[-1]
             a = np.broadcast_to(a[:, None], (N, self.num_agents, E, E))
         return a
 
-    def _obs_tuple(self, o):
-        return (o.obs.detach().cpu().numpy(), o.agent_id.detach().cpu().numpy(),
-                o.node_obs.detach().cpu().numpy(), self._adj_np(o.adj))
+    def _fetch(self, o, with_step_outputs):
+        """Device outputs -> NumPy. Returns (obs, agent_id, node_obs, adj[, reward, done])."""
+        keys = ("obs", "agent_id", "node_obs", "adj") + (("reward", "done") if with_step_outputs else ())
+        if self._pinned:
+            h = self._host[self._flip]
+            self._flip ^= 1
+            for k in keys:
+                h[k].copy_(getattr(o, k), non_blocking=True)
+            torch.cuda.current_stream(self.engine.device).synchronize()
+            arrs = [h[k].numpy() for k in keys]
+        else:
+            arrs = [getattr(o, k).detach().cpu().numpy() for k in keys]
+        arrs[3] = self._expand_adj(arrs[3])
+        return arrs
 
     # ------------------------------------------------------------------ GraphSubprocVecEnv surface
     def reset(self, num_current_episode=0):
         """-> (obs [N,A,D], agent_id [N,A,1], node_obs [N,A,E,F], adj [N,A,E,E])  (env_wrappers.py:1006-1013)"""
         o = self.engine.reset()
-        return self._obs_tuple(o)
+        return tuple(self._fetch(o, False))
 
     def step_async(self, actions, num_current_episode=None):
         """actions: [N, A, n_actions] one-hot (graph_mpe_runner.py:375-377), or [N, A] integer indices."""
@@ -135,9 +156,8 @@ class BatchedGraphMPEVecEnv(object):
             raise RuntimeError("step_wait without step_async")
         o = self._pending
         self._pending, self.waiting = None, False
-        obs, ids, node, adj = self._obs_tuple(o)                 # .cpu() synchronises the stream
-        rew = o.reward.detach().cpu().numpy()
-        done = o.done.detach().cpu().numpy().astype(bool)
+        obs, ids, node, adj, rew, done = self._fetch(o, True)    # synchronises the stream
+        done = done.astype(bool)
         infos = LazyInfos(o.info.clone(), self.num_envs, self.num_agents, include_min_time=self.cfg.max_speed > 0)
         return obs, ids, node, adj, rew, done, infos
 

@@ -97,3 +97,23 @@ def test_navigation_graph_vec_env():
         o = envs.step(np.eye(5)[np.random.RandomState(t).randint(0, 5, (16, 5))])
         assert np.isfinite(o[0]).all() and o[4].shape == (16, 5)
     envs.close()
+
+
+def test_returned_arrays_stay_valid_for_one_more_step():
+    """Pinned staging is double-buffered: what step t returned is untouched by step t+1."""
+    from gmpe.vec_env import BatchedGraphMPEVecEnv
+    envs = BatchedGraphMPEVecEnv(_args(n_rollout_threads=8), num_envs=8)
+    envs.reset()
+    a = np.zeros((8, 4), dtype=np.int64)
+    o1 = envs.step(a)
+    keep = [x.copy() for x in o1[:6]]
+    o2 = envs.step(a + 3)
+    for x, k in zip(o1[:6], keep):
+        np.testing.assert_array_equal(x, k)
+    assert not np.array_equal(o2[0], keep[0])
+    envs2 = BatchedGraphMPEVecEnv(_args(n_rollout_threads=8), num_envs=8, pinned_host=False, adj_broadcast_view=False)
+    envs2.reset()
+    p1 = envs2.step(a); p2 = envs2.step(a + 3)
+    for x, y in zip(o2[:6], p2[:6]):
+        np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+    envs.close(); envs2.close()
