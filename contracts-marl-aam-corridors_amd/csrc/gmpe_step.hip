@@ -976,67 +976,66 @@ namespace gmpe {
 // ---------------------------------------------------------------- learner-side edge set
 // process_adj (onpolicy/algorithms/utils/gnn_new.py:329-358): mask = (adj < d) & (adj > 0) on fp32
 // (inclusive=1 gives update_graph's `<=`, …_july.py:1660), edges in (batch,row,col) order, node ids
-// offset by batch*E. Three launches: per-graph count, single-block scan, ordered per-graph compaction.
+// offset by batch*E. Three launches: per-graph count (a wave per graph), chunked scan, ordered per-graph compaction.
 __device__ __forceinline__ bool edge_pred(float v, float d, int inclusive) {
     return (inclusive ? v <= d : v < d) && v > 0.0f;
 }
-__global__ __launch_bounds__(256) void k_edge_count(const float* __restrict__ adj, int EE, float d, int inclusive, int32_t* __restrict__ counts) {
-    __shared__ int wsum[4];
-    const float* g = adj + (size_t)blockIdx.x * EE;
+// one WAVE per graph (4 graphs per 256-thread block): no LDS, no barrier
+__global__ __launch_bounds__(256) void k_edge_count(const float* __restrict__ adj, int B, int EE, float d, int inclusive, int32_t* __restrict__ counts) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const float* g = adj + (size_t)b * EE;
     int c = 0;
-    for (int q = threadIdx.x; q < EE; q += 256) c += edge_pred(g[q], d, inclusive) ? 1 : 0;
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-__global__ __launch_bounds__(1024) void k_edge_scan(const int32_t* __restrict__ counts, int B, int32_t* __restrict__ offsets, int32_t* __restrict__ total) {
-    __shared__ int part[1024];
-    const int t = threadIdx.x;
-    const int per = (B + 1023) / 1024;
-    const int lo = t * per, hi = min(B, lo + per);
-    int s = 0;
-    for (int q = lo; q < hi; ++q) s += counts[q];
-    part[t] = s;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {                    // Hillis-Steele inclusive scan
-        const int v = t >= o ? part[t - o] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    for (int q0 = 0; q0 < EE; q0 += 64) {
+        const int q = q0 + lane;
+        c += __popcll(__ballot(q < EE && edge_pred(g[q < EE ? q : 0], d, inclusive)));
     }
-    int run = t ? part[t - 1] : 0;
-    for (int q = lo; q < hi; ++q) { offsets[q] = run; run += counts[q]; }
-    if (t == 1023) *total = part[1023];
+    if (lane == 0) counts[b] = c;
 }
-__global__ __launch_bounds__(256) void k_edge_write(const float* __restrict__ adj, int E, float d, int inclusive,
+// exclusive scan of the per-graph counts: one 1024-thread block per chunk of 1024 graphs. The chunk's base is the sum
+// of ALL preceding counts, re-reduced by the block itself (L2-resident, <= B reads: no atomics, no extra pass); inside
+// the chunk a wave-shuffle scan + 16 wave totals.
+__global__ __launch_bounds__(1024) void k_edge_scan(const int32_t* __restrict__ counts, int B, int32_t* __restrict__ offsets, int32_t* __restrict__ total) {
+    __shared__ int wtot[16];
+    __shared__ int wbase[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int first = blockIdx.x * 1024, b = first + t;
+    int part = 0;
+    for (int q = t; q < first; q += 1024) part += counts[q];
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+    const int c = b < B ? counts[b] : 0;
+    int incl = c;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    if (lane == 0) wbase[w] = part;
+    if (lane == 63) wtot[w] = incl;
+    __syncthreads();
+    int pre = 0;
+    for (int k = 0; k < 16; ++k) pre += wbase[k];
+    for (int k = 0; k < w; ++k) pre += wtot[k];
+    if (b < B) offsets[b] = pre + incl - c;
+    if (blockIdx.x == gridDim.x - 1 && t == 1023) *total = pre + incl;
+}
+__global__ __launch_bounds__(256) void k_edge_write(const float* __restrict__ adj, int B, int E, float d, int inclusive,
                                                     const int32_t* __restrict__ offsets, int32_t* __restrict__ edge_index,
                                                     float* __restrict__ edge_attr, int cap) {
-    __shared__ int wtot[4];
-    __shared__ int base_s;
-    const int EE = E * E, b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const int EE = E * E;
     const float* g = adj + (size_t)b * EE;
-    if (t == 0) base_s = offsets[b];
-    __syncthreads();
-    for (int q0 = 0; q0 < EE; q0 += 256) {
-        const int q = q0 + t;
+    int base = offsets[b];                                   // wave-uniform running position: (batch,row,col) order
+    for (int q0 = 0; q0 < EE; q0 += 64) {
+        const int q = q0 + lane;
         const float v = q < EE ? g[q] : 0.0f;
         const bool f = q < EE && edge_pred(v, d, inclusive);
         const unsigned long long bal = __ballot(f);
-        if (lane == 0) wtot[w] = __popcll(bal);
-        __syncthreads();
-        int pre = __popcll(bal & ((1ull << lane) - 1ull));
-        for (int k = 0; k < w; ++k) pre += wtot[k];
-        const int pos = base_s + pre;
+        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
         if (f && pos < cap) {
             const int r = q / E, cc = q - r * E;
             edge_index[pos] = b * E + r;
             edge_index[cap + pos] = b * E + cc;
             edge_attr[pos] = v;
         }
-        __syncthreads();
-        if (t == 0) base_s += wtot[0] + wtot[1] + wtot[2] + wtot[3];
-        __syncthreads();
+        base += __popcll(bal);
     }
 }
 
@@ -1063,7 +1062,7 @@ struct gmpe_handle {
     int spec = 0;
     unsigned long long* stamps = nullptr;
     hipEvent_t region_ev[2] = {nullptr, nullptr};
-    int32_t* edge_ws = nullptr;      // [2*cap_graphs] counts | offsets
+    int32_t* edge_ws = nullptr;      // [cap_graphs] counts | [cap_graphs] offsets | [cap_graphs/1024+2] chunk sums
     size_t edge_ws_graphs = 0;
 };
 
@@ -1362,14 +1361,14 @@ int gmpe_edges_from_adj(gmpe_handle* h, const float* adj_dev, int32_t batch, int
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (h->edge_ws_graphs < (size_t)batch) {                 // workspace grows on first use only
         if (h->edge_ws) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(h->edge_ws)); h->edge_ws = nullptr; }
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->edge_ws), sizeof(int32_t) * 2 * (size_t)batch));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->edge_ws), sizeof(int32_t) * (2 * (size_t)batch + (size_t)batch / 1024 + 2)));
         h->edge_ws_graphs = batch;
     }
     int32_t* counts = h->edge_ws; int32_t* offsets = h->edge_ws + h->edge_ws_graphs;
-    const int EE = num_nodes * num_nodes;
-    hipLaunchKernelGGL(k_edge_count, dim3(batch), dim3(256), 0, st, adj_dev, EE, max_edge_dist, inclusive, counts);
-    hipLaunchKernelGGL(k_edge_scan, dim3(1), dim3(1024), 0, st, counts, batch, offsets, n_edges_dev);
-    hipLaunchKernelGGL(k_edge_write, dim3(batch), dim3(256), 0, st, adj_dev, num_nodes, max_edge_dist, inclusive, offsets,
+    const int EE = num_nodes * num_nodes, nchunks = (batch + 1023) / 1024;
+    hipLaunchKernelGGL(k_edge_count, dim3((batch + 3) / 4), dim3(256), 0, st, adj_dev, batch, EE, max_edge_dist, inclusive, counts);
+    hipLaunchKernelGGL(k_edge_scan, dim3(nchunks), dim3(1024), 0, st, counts, batch, offsets, n_edges_dev);
+    hipLaunchKernelGGL(k_edge_write, dim3((batch + 3) / 4), dim3(256), 0, st, adj_dev, batch, num_nodes, max_edge_dist, inclusive, offsets,
                        edge_index_dev, edge_attr_dev, cap);
     HIPCHK(hipGetLastError());
     return GMPE_OK;

@@ -374,3 +374,22 @@ def test_packed_tiles_with_staggered_resets_vs_oracle(monkeypatch, G, B, scen):
         seen_mixed |= bool(((tiles.sum(1) > 0) & (tiles.sum(1) < G)).any())
     assert seen_mixed
     eng.check_errors()
+
+
+def test_edges_from_adj_many_graphs_and_caps():
+    """More than one scan chunk (B > 1024 graphs), ragged sizes, and a cap smaller than the edge count."""
+    import torch
+    eng = _engine(gmpe.make_config(num_envs=4, num_agents=3, seed=4))
+    rng = np.random.RandomState(3)
+    for B, E in ((2500, 7), (1025, 20), (3, 33)):
+        adj = (rng.rand(B, E, E) * 2.0).astype(np.float32)
+        adj[rng.rand(B, E, E) < 0.3] = 0.0
+        t = torch.as_tensor(adj, device="cuda")
+        ei, ea, m = eng.edges_from_adj(t, 1.0)
+        e_ref, w_ref = edges_numpy(adj, np.float32(1.0), False)
+        assert m == e_ref.shape[1]
+        np.testing.assert_array_equal(_np(ei), e_ref); np.testing.assert_array_equal(_np(ea), w_ref)
+        cap = max(1, m // 3)
+        ei2, ea2, m2 = eng.edges_from_adj(t, 1.0, cap=cap)
+        assert m2 == m and ei2.shape[1] == cap
+        np.testing.assert_array_equal(_np(ei2), e_ref[:, :cap]); np.testing.assert_array_equal(_np(ea2), w_ref[:cap])
