@@ -14,15 +14,17 @@ NODE_FEATS = 8
 INFO_KEYS = ["individual_reward", "Dist_to_goal", "Time_req_to_goal", "Num_agent_collisions",
              "Num_obst_collisions", "Distance_mean", "Distance_variance", "Mean_by_variance",
              "Dists_traveled", "Time_taken", "Time_mean", "Time_stddev", "Time_mean_by_stddev",
-             "Conformance", "Delta_spacing", "Spacing_violations", "Min_time_to_goal"]
+             "Conformance", "Delta_spacing", "Spacing_violations", "Min_time_to_goal", "Phase_reached"]
 MAX_WALLS = 8
 TUBE_STRIDE = 12
 
 SCENARIO_NAVIGATION_GRAPH = 0
 SCENARIO_TUBE_JULY = 1
+SCENARIO_ROT_INV = 2
 SCENARIOS = {
     "navigation_graph": SCENARIO_NAVIGATION_GRAPH,
     "nav_metered_one_goal_graph_rotate_tube_july": SCENARIO_TUBE_JULY,
+    "nav_graph_metered_single_corridor_rot_inv": SCENARIO_ROT_INV,
 }
 DYN_DOUBLE_INTEGRATOR, DYN_UNICYCLE, DYN_AIR_TAXI = 0, 1, 2
 DYNAMICS = {"double_integrator": DYN_DOUBLE_INTEGRATOR, "unicycle_vehicle": DYN_UNICYCLE,
@@ -103,6 +105,10 @@ class GmpeConfig(C.Structure):
     def obs_dim(self):
         return 19 if self.scenario == SCENARIO_TUBE_JULY else 13
 
+    @property
+    def node_feats(self):
+        return 7 if self.scenario == SCENARIO_ROT_INV else NODE_FEATS
+
 
 def default_walls(world_size, num_walls):
     """SURVEY.md §8(d) wall set for navigation_graph: H at y=±ws/2, V at x=±ws/2, width 0.1."""
@@ -122,12 +128,12 @@ def make_config(scenario_name="nav_metered_one_goal_graph_rotate_tube_july", dyn
                                   % (scenario_name, sorted(SCENARIOS)))
     scen = SCENARIOS[scenario_name]
     if dynamics_type is None:
-        dynamics_type = "air_taxi" if scen == SCENARIO_TUBE_JULY else "double_integrator"
+        dynamics_type = "double_integrator" if scen == SCENARIO_NAVIGATION_GRAPH else "air_taxi"
     if dynamics_type not in DYNAMICS:
         raise NotImplementedError("dynamics_type %r" % (dynamics_type,))
     dyn = DYNAMICS[dynamics_type]
-    if scen == SCENARIO_TUBE_JULY and dyn == DYN_DOUBLE_INTEGRATOR:
-        raise NotImplementedError("the tube scenario is kinematic (air_taxi / unicycle_vehicle)")
+    if scen != SCENARIO_NAVIGATION_GRAPH and dyn == DYN_DOUBLE_INTEGRATOR:
+        raise NotImplementedError("the tube scenarios are kinematic (air_taxi / unicycle_vehicle)")
     if scen == SCENARIO_NAVIGATION_GRAPH and dyn != DYN_DOUBLE_INTEGRATOR:
         raise NotImplementedError("navigation_graph uses the double_integrator force path")
     dc = _DYN_CFG[dyn]
@@ -211,11 +217,12 @@ for _i, (_name, _dt, _shape) in enumerate([
         ("times_required", np.int32, _na), ("dists_to_goal", np.int32, _na), ("dist_left", np.int32, _na),
         ("goal_reached", np.int32, _na), ("n_agent_coll", np.int32, _na), ("n_obst_coll", np.int32, _na),
         ("spacing_viol", np.int32, _na), ("steps_in_corr", np.int32, _na), ("conformance", np.int32, _na),
-        ("goal_min_time", np.float64, _na), ("delta_spacing", np.float64, _n), ("error_flags", np.int32, _n)]):
+        ("goal_min_time", np.float64, _na), ("delta_spacing", np.float64, _n), ("error_flags", np.int32, _n),
+        ("prev_proj", np.float64, _na)]):
     FIELDS[_name] = (_i, np.dtype(_dt), _shape)
 
 
 def algorithmic_bytes_per_env_step(cfg):
     """B = 4*A*(E^2 + E*F + D + 2) + A + 4*A + 2*A*S, S = 48 B/agent."""
-    A, E, F, D = cfg.num_agents, cfg.num_entities, NODE_FEATS, cfg.obs_dim
+    A, E, F, D = cfg.num_agents, cfg.num_entities, cfg.node_feats, cfg.obs_dim
     return 4 * A * (E * E + E * F + D + 2) + A + 4 * A + 2 * A * 48

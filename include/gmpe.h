@@ -19,7 +19,7 @@
  *  - one handle per GPU; handles are not thread-safe.
  *
  * Shapes: N envs, A agents, L landmarks, O obstacles, E = A+L+O graph nodes, F = 8 node features,
- * D = observation width (19 tube_july, 13 navigation_graph).
+ * D = observation width (19 tube_july, 13 navigation_graph, 13 rot_inv); F = 8 (7 for rot_inv).
  */
 #ifndef GMPE_H
 #define GMPE_H
@@ -32,8 +32,8 @@ extern "C" {
 #endif
 
 #define GMPE_ABI_VERSION 1
-#define GMPE_NODE_FEATS 8          /* …_july.py:1771  [rel_vel2, rel_pos2, rel_goal2, occupied, type] */
-#define GMPE_INFO_KEYS 17          /* …_july.py:806-828 + 'individual_reward' (environment.py:1048)  */
+#define GMPE_NODE_FEATS 8          /* …_july.py:1771  [rel_vel2, rel_pos2, rel_goal2, occupied, type]; rot_inv: 7 (gmpe_node_feats) */
+#define GMPE_INFO_KEYS 18          /* …_july.py:806-828 + 'individual_reward' (environment.py:1048) + 'Phase_reached' (rot_inv:835) */
 #define GMPE_MAX_AGENTS 64         /* one wavefront lane per agent in the sequential-semantics pass   */
 #define GMPE_MAX_ENTITIES 160
 #define GMPE_MAX_WALLS 8
@@ -53,7 +53,9 @@ typedef enum gmpe_status {
 typedef enum gmpe_scenario {
     GMPE_SCENARIO_NAVIGATION_GRAPH = 0, /* not shipped by the reference (train_mpe.py:72-73 default only):
                                            restated from extant blocks, see DESIGN.md §navigation_graph */
-    GMPE_SCENARIO_TUBE_JULY = 1         /* nav_metered_one_goal_graph_rotate_tube_july.py               */
+    GMPE_SCENARIO_TUBE_JULY = 1,        /* nav_metered_one_goal_graph_rotate_tube_july.py               */
+    GMPE_SCENARIO_ROT_INV = 2           /* nav_graph_metered_single_corridor_rot_inv.py: rotation-
+                                           invariant 13-d obs, 7 node features, exit gate + progress reward, armed cooldown */
 } gmpe_scenario;
 
 /* Dynamics (multiagent/core.py:23-26 EntityDynamicsType). */
@@ -138,6 +140,7 @@ typedef enum gmpe_field {
     GMPE_F_GOAL_MIN_TIME,    /* f64 [N,A] agent.goal_min_time (…_july.py:941-951)                       */
     GMPE_F_DELTA_SPACING,    /* f64 [N]   running sum of the delta_spacing list (:1180, :802)           */
     GMPE_F_ERROR_FLAGS,      /* i32 [N]   sticky: bit0 tape exhausted, bit1 placement gave up           */
+    GMPE_F_PREV_PROJ,        /* f64 [N,A] rot_inv: prev_proj (a float32 array in the reference, :374, 1268-1276) */
     GMPE_F_COUNT
 } gmpe_field;
 
@@ -149,7 +152,7 @@ typedef struct gmpe_handle gmpe_handle;
 typedef struct gmpe_outputs {
     float*   obs;        /* [N,A,D]                                                                    */
     int32_t* agent_id;   /* [N,A,1]                    (…_july.py:1554-1555)                           */
-    float*   node_obs;   /* [N,A,E,F]                  (…_july.py:1584-1624, 1694-1771)                */
+    float*   node_obs;   /* [N,A,E,F]  F = gmpe_node_feats (…_july.py:1584-1624, 1694-1771)            */
     float*   adj;        /* adj_compact ? [N,E,E] : [N,A,E,E]  (…_july.py:1625-1648)                   */
     float*   reward;     /* [N,A]   (step only)        (…_july.py:1105-1221)                           */
     uint8_t* done;       /* [N,A]   (step only)        (environment.py:264-271)                        */
@@ -161,8 +164,9 @@ typedef struct gmpe_outputs {
 int gmpe_abi_version(void);
 const char* gmpe_last_error(void);
 
-/* Observation width D and node count E for a config (no device needed). */
+/* Observation width D, node feature count F and node count E for a config (no device needed). */
 int gmpe_obs_dim(const gmpe_config* cfg);
+int gmpe_node_feats(const gmpe_config* cfg);
 int gmpe_num_entities(const gmpe_config* cfg);
 
 /* Create the engine on HIP device `device`. Replaces N x `GraphMPEEnv(args)` + `env.seed(seed +

@@ -30,8 +30,8 @@
 
 typedef struct gmpo {
     gmpe_config c;
-    int N, A, L, O, E, D;
-    double *x, *y, *s2, *s3, *p_dist, *time;
+    int N, A, L, O, E, D, F;
+    double *x, *y, *s2, *s3, *p_dist, *time, *prev_proj;
     uint8_t* status;
     int32_t *prev_phase, *phase_reached, *cooldown, *goal_tracker;
     int32_t* current_step;
@@ -96,6 +96,8 @@ static inline double logaddexp0(double x) {
 static inline int is_kinematic(const gmpo* h) { return h->c.dynamics != GMPE_DYN_DOUBLE_INTEGRATOR; }
 
 int gmpo_obs_dim(const gmpe_config* c) { return c->scenario == GMPE_SCENARIO_TUBE_JULY ? 19 : 13; }
+int gmpo_node_feats(const gmpe_config* c) { return c->scenario == GMPE_SCENARIO_ROT_INV ? 7 : 8; }
+static inline int is_tube(const gmpe_config* c) { return c->scenario != GMPE_SCENARIO_NAVIGATION_GRAPH; }
 int gmpo_num_entities(const gmpe_config* c) { return c->num_agents + c->num_landmarks + c->num_obstacles; }
 
 /* ------------------------------------------------------------------ create / fields */
@@ -110,10 +112,10 @@ int gmpo_create(const gmpe_config* cfg, gmpo** out) {
     gmpo* h = (gmpo*)calloc(1, sizeof(gmpo));
     h->c = *cfg;
     h->N = cfg->num_envs; h->A = cfg->num_agents; h->L = cfg->num_landmarks; h->O = cfg->num_obstacles;
-    h->E = gmpo_num_entities(cfg); h->D = gmpo_obs_dim(cfg);
+    h->E = gmpo_num_entities(cfg); h->D = gmpo_obs_dim(cfg); h->F = gmpo_node_feats(cfg);
     const size_t NA = (size_t)h->N * h->A;
     ALLOC(h->x, NA, double); ALLOC(h->y, NA, double); ALLOC(h->s2, NA, double); ALLOC(h->s3, NA, double);
-    ALLOC(h->p_dist, NA, double); ALLOC(h->time, NA, double); ALLOC(h->status, NA, uint8_t);
+    ALLOC(h->p_dist, NA, double); ALLOC(h->time, NA, double); ALLOC(h->prev_proj, NA, double); ALLOC(h->status, NA, uint8_t);
     ALLOC(h->prev_phase, NA, int32_t); ALLOC(h->phase_reached, NA, int32_t); ALLOC(h->cooldown, NA, int32_t);
     ALLOC(h->goal_tracker, NA, int32_t); ALLOC(h->current_step, h->N, int32_t); ALLOC(h->rng_ctr, h->N, int64_t);
     ALLOC(h->tube, (size_t)h->N * GMPE_TUBE_STRIDE, double); ALLOC(h->landmarks, (size_t)h->N * h->L * 2, double);
@@ -129,7 +131,7 @@ int gmpo_create(const gmpe_config* cfg, gmpo** out) {
 }
 int gmpo_destroy(gmpo* h) {
     if (!h) return GMPE_OK;
-    void* ps[] = {h->x, h->y, h->s2, h->s3, h->p_dist, h->time, h->status, h->prev_phase, h->phase_reached,
+    void* ps[] = {h->prev_proj, h->x, h->y, h->s2, h->s3, h->p_dist, h->time, h->status, h->prev_phase, h->phase_reached,
                   h->cooldown, h->goal_tracker, h->current_step, h->rng_ctr, h->tube, h->landmarks, h->obstacles,
                   h->times_required, h->dists_to_goal, h->dist_left, h->goal_reached, h->n_agent_coll,
                   h->n_obst_coll, h->spacing_viol, h->steps_in_corr, h->conformance, h->goal_min_time,
@@ -169,6 +171,7 @@ static int field_ptr(gmpo* h, int f, void** p, size_t* bytes) {
         case GMPE_F_GOAL_MIN_TIME: *p = h->goal_min_time; *bytes = NA * 8; break;
         case GMPE_F_DELTA_SPACING: *p = h->delta_spacing; *bytes = N * 8; break;
         case GMPE_F_ERROR_FLAGS: *p = h->error_flags; *bytes = N * 4; break;
+        case GMPE_F_PREV_PROJ: *p = h->prev_proj; *bytes = NA * 8; break;
         default: snprintf(g_err, sizeof g_err, "unknown field %d", f); return GMPE_ERR_INVALID_ARG;
     }
     return GMPE_OK;
@@ -191,7 +194,7 @@ int gmpo_get_dist_cache(gmpo* h, double* dst) { memcpy(dst, h->dist, (size_t)h->
 /* ------------------------------------------------------------------ per-env view */
 typedef struct envv {
     gmpo* h; int n, A, L, O, E;
-    double *x, *y, *s2, *s3, *p_dist, *time; uint8_t* status;
+    double *x, *y, *s2, *s3, *p_dist, *time, *prev_proj; uint8_t* status;
     int32_t *prev_phase, *phase_reached, *cooldown, *goal_tracker;
     double *tube, *lm, *ob, *dist;
     int32_t *times_required, *dists_to_goal, *dist_left, *goal_reached, *n_agent_coll, *n_obst_coll,
@@ -201,7 +204,7 @@ typedef struct envv {
 static envv view(gmpo* h, int n) {
     envv v; const size_t o = (size_t)n * h->A;
     v.h = h; v.n = n; v.A = h->A; v.L = h->L; v.O = h->O; v.E = h->E;
-    v.x = h->x + o; v.y = h->y + o; v.s2 = h->s2 + o; v.s3 = h->s3 + o; v.p_dist = h->p_dist + o; v.time = h->time + o;
+    v.x = h->x + o; v.y = h->y + o; v.s2 = h->s2 + o; v.s3 = h->s3 + o; v.p_dist = h->p_dist + o; v.time = h->time + o; v.prev_proj = h->prev_proj + o;
     v.status = h->status + o; v.prev_phase = h->prev_phase + o; v.phase_reached = h->phase_reached + o;
     v.cooldown = h->cooldown + o; v.goal_tracker = h->goal_tracker + o;
     v.tube = h->tube + (size_t)n * GMPE_TUBE_STRIDE; v.lm = h->landmarks + (size_t)n * h->L * 2;
@@ -398,6 +401,153 @@ static int get_agent_phase(envv* v, int i) {
     }
 }
 
+static double goal_block(envv* v, int i);
+static double collision_block(envv* v, int i);
+
+/* ------------------------------------------------------------------ rot_inv geometry + phase
+ * nav_graph_metered_single_corridor_rot_inv.py:639-669 (gates), 675-739 (get_agent_phase). */
+static double entrance_gate_distance(double s, double y, double hw) {       /* :646-652 */
+    const double cy = clipd(y, -hw, hw);
+    return hypot(fabs(s), y - cy);
+}
+static double exit_gate_distance(double s, double y, double L, double hw) { /* :660-669, penalize_backward=False */
+    const double cy = clipd(y, -hw, hw);
+    const double ds = (L - s) > 0.0 ? (L - s) : 0.0;
+    return hypot(ds, y - cy);
+}
+static int in_tube_rect(double s, double y, double L, double hw) { const double eps = 0.05; return (-eps <= s && s <= L + eps) && (fabs(y) <= hw + eps); }
+static int in_entrance_gate(double s, double y, double L, double hw) {
+    const double eps = 0.05, gf = 0.08 * L, gb = 0.02 * L;
+    return (-gb - eps <= s && s <= gf + eps) && (fabs(y) <= hw + eps);
+}
+static int in_exit_gate(double s, double y, double L, double hw) {            /* :654-658 */
+    const double eps = 0.05, eb = 0.05 * L, ef = 0.08 * L;
+    return (L - eb - eps <= s && s <= L + ef + eps) && (fabs(y) <= hw + eps);
+}
+/* rot_inv get_agent_phase: mutates only the cooldown; depends on previous_phase AND phase_reached. */
+static int get_agent_phase_rot(envv* v, int i) {
+    const double L = v->tube[T_L], hw = v->tube[T_HALFW];
+    double s, yy; tube_coords(v, v->x[i], v->y[i], &s, &yy);
+    const int in_tube = in_tube_rect(s, yy, L, hw), passed = s > L;
+    const int valid_entrance = in_entrance_gate(s, yy, L, hw), valid_exit = in_exit_gate(s, yy, L, hw);
+    if (v->cooldown[i] > 0) v->cooldown[i] -= 1;
+    if (!in_tube && !passed) return 0;
+    else if (in_tube) { if (v->prev_phase[i] == 0) return valid_entrance ? 1 : 0; return 1; }
+    if (passed) {
+        if (v->phase_reached[i] >= 1) {
+            if (v->prev_phase[i] == 1 && valid_exit) return 2;
+            else if (v->prev_phase[i] == 2) return 2;
+            return 0;
+        }
+    }
+    return 0;
+}
+/* get_rotated_position_from_relative (…rot_inv.py:91-97): [[c, s], [-s, c]] @ v */
+static void rotate(double th, double vx, double vy, double* ox, double* oy) {
+    const double c = cos(th), s = sin(th);
+    *ox = c * vx + s * vy; *oy = -s * vx + c * vy;
+}
+#define F32(x) ((double)(float)(x))
+/* Scenario.observation, …rot_inv.py:1453-1548 — 13 floats, every entry rounded to float32 like the reference. */
+static void observation_rot(envv* v, int i, double* o) {
+    const int A = v->A;
+    const double px = v->x[i], py = v->y[i], th = v->s2[i];
+    double gx, gy; rotate(th, v->lm[2 * i] - px, v->lm[2 * i + 1] - py, &gx, &gy);
+    int b1 = -1, b2 = -1; double d1 = 0, d2 = 0;
+    for (int k = 0; k < A; ++k) {
+        if (k == i) continue;
+        const double d = norm2(v->x[k] - px, v->y[k] - py);
+        if (b1 < 0 || d < d1) { b2 = b1; d2 = d1; b1 = k; d1 = d; }
+        else if (b2 < 0 || d < d2) { b2 = k; d2 = d; }
+    }
+    double n1x = 0, n1y = 0, n2x = 0, n2y = 0;
+    if (b1 >= 0) rotate(th, F32(v->x[b1] - px), F32(v->y[b1] - py), &n1x, &n1y);   /* rel vec cast to float32 BEFORE the rotation */
+    if (b2 >= 0) rotate(th, F32(v->x[b2] - px), F32(v->y[b2] - py), &n2x, &n2y);
+    const int phase = get_agent_phase_rot(v, i);
+    const double L = v->tube[T_L], hw = v->tube[T_HALFW];
+    double s, yy; tube_coords(v, px, py, &s, &yy);
+    o[0] = F32(cos(th)); o[1] = F32(sin(th)); o[2] = F32(v->s3[i]);
+    o[3] = F32(gx); o[4] = F32(gy); o[5] = F32(n1x); o[6] = F32(n1y); o[7] = F32(n2x); o[8] = F32(n2y);
+    o[9] = F32(clipd(s / L, -2.0, 2.0)); o[10] = F32(clipd(yy / (hw + 1e-9), -2.0, 2.0));
+    o[11] = F32(exit_gate_distance(s, yy, L, hw) / (L + 1e-9)); o[12] = (double)phase;
+}
+/* Scenario.reward, …rot_inv.py:1122-1338 */
+static double reward_rot(envv* v, int i) {
+    const gmpe_config* c = &v->h->c;
+    const int A = v->A;
+    double rew = 0;
+    int cp = get_agent_phase_rot(v, i);
+    rew += collision_block(v, i);
+    const double tdx = v->tube[T_EXX] - v->tube[T_ENTX], tdy = v->tube[T_EXY] - v->tube[T_ENTY];
+    const double tlen = sqrt(tdx * tdx + tdy * tdy);
+    const double px = v->x[i], py = v->y[i];
+    const double hx = cos(v->s2[i]), hy = sin(v->s2[i]);
+    const double L = v->tube[T_L], hw = v->tube[T_HALFW];
+    double s, yy; tube_coords(v, px, py, &s, &yy);
+    int front = -1, back = -1; double fproj = 0, bproj = 0;
+    for (int k = 0; k < A; ++k) {
+        if (k == i) continue;
+        const double pj = (v->x[k] - px) * hx + (v->y[k] - py) * hy;
+        if (pj > 0) { if (front < 0 || pj < fproj) { front = k; fproj = pj; } }
+        else { if (back < 0 || pj > bproj) { back = k; bproj = pj; } }
+    }
+    if (cp == 2 && cp > v->prev_phase[i] + 1) rew -= c->goal_rew;
+    const double ux = tdx / tlen, uy = tdy / tlen;
+    const double proj = (px - v->tube[T_ENTX]) * ux + (py - v->tube[T_ENTY]) * uy;
+    if (cp == v->prev_phase[i] + 1 && v->phase_reached[i] == cp - 1) {
+        if (cp == 1 && in_entrance_gate(s, yy, L, hw) && v->cooldown[i] == 0) {
+            rew += c->goal_rew;
+            v->cooldown[i] = (int32_t)((double)c->episode_length / 10);       /* float assigned into an int32 array (:1200, :228) */
+            v->phase_reached[i] = 1;
+        } else if (cp == 2) { rew += c->goal_rew; v->phase_reached[i] = 2; }
+    }
+    if (cp == 0) rew -= entrance_gate_distance(s, yy, hw);
+    else if (cp == 1) {
+        double err = 0;
+        if (front >= 0) { const double diff = norm2(v->x[front] - px, v->y[front] - py) - c->sep_dist; err += diff < 0 ? fabs(diff) : 0; }
+        if (back >= 0) { const double diff = norm2(v->x[back] - px, v->y[back] - py) - c->sep_dist; err += diff < 0 ? fabs(diff) : 0; }
+        if (err > 0) v->spacing_viol[i] += 1;
+        rew -= err * c->formation_rew;
+        rew -= exit_gate_distance(s, yy, L, hw);
+        const double progress_gain = c->goal_rew / (c->world_size * 0.8 * 10);   /* :522 goal_rew / (tube_length*10) */
+        const double dproj = proj - v->prev_proj[i];
+        rew += progress_gain * (dproj > -0.05 ? dproj : -0.05);
+        v->h->delta_spacing[v->n] += err;
+        v->steps_in_corr[i] += 1;
+        v->prev_proj[i] = F32(proj);                                            /* prev_proj is a float32 array (:374) */
+    } else if (cp == 2 && v->phase_reached[i] == 0) cp = 0;
+    else if (cp == 2) rew += goal_block(v, i);
+    if (v->phase_reached[i] == 1 && cp == 0) v->conformance[i] += 1;
+    if (cp > v->phase_reached[i]) v->phase_reached[i] = cp;
+    if (cp < v->prev_phase[i]) rew -= c->collision_rew;
+    if (cp < v->phase_reached[i]) rew -= c->collision_rew;
+    v->prev_phase[i] = cp;
+    if (in_tube_rect(s, yy, L, hw) && cp != 1) rew -= c->collision_rew;
+    if (s > L && v->phase_reached[i] < 1) rew -= c->goal_rew;
+    return clipd(rew, -4 * c->collision_rew, c->goal_rew * 5);
+}
+/* _get_entity_feat_relative, …rot_inv.py:1690-1766: float32 positions/velocities, differences in float32, rotated by
+ * the ego heading in float64, rounded to float32. node: [E,7]. The adjacency part is shared with the July file. */
+static void node_features_rot(envv* v, int i, double* node) {
+    const int A = v->A, L = v->L, E = v->E;
+    double evx, evy; agent_vel(v, i, &evx, &evy);
+    const float apx = (float)v->x[i], apy = (float)v->y[i], avx = (float)evx, avy = (float)evy;
+    const double th = v->s2[i];
+    for (int k = 0; k < E; ++k) {
+        double kx, ky, kvx = 0.0, kvy = 0.0; ent_pos(v, k, &kx, &ky);
+        if (k < A) agent_vel(v, k, &kvx, &kvy);
+        const float rpx = (float)kx - apx, rpy = (float)ky - apy, rvx = (float)kvx - avx, rvy = (float)kvy - avy;
+        double* r = node + 7 * k;
+        double ox, oy;
+        rotate(th, (double)rvx, (double)rvy, &ox, &oy); r[0] = F32(ox); r[1] = F32(oy);
+        rotate(th, (double)rpx, (double)rpy, &ox, &oy); r[2] = F32(ox); r[3] = F32(oy);
+        if (k < A) {
+            const float gx = (float)v->lm[2 * k] - apx, gy = (float)v->lm[2 * k + 1] - apy;
+            rotate(th, (double)gx, (double)gy, &ox, &oy); r[4] = F32(ox); r[5] = F32(oy); r[6] = 0.0;
+        } else { r[4] = r[2]; r[5] = r[3]; r[6] = k < A + L ? 1.0 : 2.0; }
+    }
+}
+
 /* ------------------------------------------------------------------ observation */
 /* Scenario.observation, …_july.py:1337-1463 (navigation_graph: slice [0:13]). */
 static void observation(envv* v, int i, double* o) {
@@ -510,6 +660,8 @@ static double reward_nav(envv* v, int i) {
  * node: [E,8] for ego i. The adjacency is world.cached_dist_mag itself, masked IN PLACE. */
 static void graph_observation(envv* v, int i, double* node) {
     const int A = v->A, L = v->L, E = v->E;
+    if (v->h->c.scenario == GMPE_SCENARIO_ROT_INV) { node_features_rot(v, i, node); goto mask; }
+    {
     double evx, evy; agent_vel(v, i, &evx, &evy);
     const double px = v->x[i], py = v->y[i];
     for (int k = 0; k < E; ++k) {
@@ -520,6 +672,8 @@ static void graph_observation(envv* v, int i, double* node) {
         if (k < A) { r[4] = v->lm[2 * k] - px; r[5] = v->lm[2 * k + 1] - py; r[6] = 0.0; r[7] = 0.0; }
         else { r[4] = r[2]; r[5] = r[3]; r[6] = 1.0; r[7] = k < A + L ? 1.0 : 2.0; }
     }
+    }
+mask:
     for (int k = 0; k < A + L; ++k) {                    /* mask sized to E: obstacle rows never masked */
         int off;
         if (k < A) off = v->status[k];
@@ -563,6 +717,7 @@ static void info_callback(envv* v, int i, double rew, double* out) {
     out[14] = v->h->delta_spacing[v->n] / (svsum != 0 ? svsum : 1);
     out[15] = (double)v->spacing_viol[i] / (v->steps_in_corr[i] != 0 ? v->steps_in_corr[i] : 1);
     out[16] = v->goal_min_time[i];
+    out[17] = v->phase_reached[i];                        /* 'Phase_reached' (rot_inv.py:835) */
 }
 
 /* ------------------------------------------------------------------ reset */
@@ -571,7 +726,7 @@ static void reset_counters(envv* v) {             /* reset_world, …_july.py:33
         v->times_required[i] = -1; v->dists_to_goal[i] = -1; v->dist_left[i] = -1; v->n_obst_coll[i] = 0;
         v->n_agent_coll[i] = 0; v->goal_reached[i] = -1; v->goal_tracker[i] = -1; v->conformance[i] = 0;
         v->spacing_viol[i] = 0; v->steps_in_corr[i] = 0; v->phase_reached[i] = 0; v->cooldown[i] = 0;
-        v->p_dist[i] = 0.0; v->time[i] = 0.0;
+        v->p_dist[i] = 0.0; v->time[i] = 0.0; v->prev_proj[i] = 0.0;
     }
     v->h->delta_spacing[v->n] = 0.0;
 }
@@ -607,8 +762,10 @@ static void reset_world_july(envv* v) {
     int k = 0, tries = 0;
     while (k < v->A) {                                                /* random_scenario 452-486 */
         const double u0 = draw(h, n), u1 = draw(h, n);
-        const double jx = 0.2 * (-ws + (ws - (-ws)) * u0), jy = 0.2 * (-ws + (ws - (-ws)) * u1);
-        const double dfe = (ws + k) / 5;
+        const int rot = c->scenario == GMPE_SCENARIO_ROT_INV;                /* rot_inv.py:463, 469: 0.3 and /3 */
+        const double jf = rot ? 0.3 : 0.2;
+        const double jx = jf * (-ws + (ws - (-ws)) * u0), jy = jf * (-ws + (ws - (-ws)) * u1);
+        const double dfe = rot ? (ws + k) / 3 : (ws + k) / 5;
         const double px = entx + dfe * sa + jx, py = enty + dfe * ca + jy;
         int bad = is_obstacle_collision(v, px, py, size);
         for (int q = 0; q < k && !bad; ++q) if (norm2(v->x[q] - px, v->y[q] - py) < c->sep_dist) bad = 1;   /* 895-904 */
@@ -664,15 +821,16 @@ static void reset_world_nav(envv* v) {
 static void env_reset(envv* v, double* obs, int32_t* ids, double* node, double* adj) {
     gmpo* h = v->h; const int A = v->A, E = v->E, D = h->D;
     h->current_step[v->n] = 0;
-    if (h->c.scenario == GMPE_SCENARIO_TUBE_JULY) reset_world_july(v); else reset_world_nav(v);
+    if (is_tube(&h->c)) reset_world_july(v); else reset_world_nav(v);
     calculate_distances(v);                     /* initialize_min_time_distance_graph (735-739) */
     double otmp[32], ntmp[GMPE_MAX_ENTITIES * 8];
+    const int F = h->F, rotinv = h->c.scenario == GMPE_SCENARIO_ROT_INV;
     for (int i = 0; i < A; ++i) {
-        observation(v, i, otmp);
+        if (rotinv) observation_rot(v, i, otmp); else observation(v, i, otmp);
         graph_observation(v, i, ntmp);
         if (obs) memcpy(obs + (size_t)i * D, otmp, sizeof(double) * D);
         if (ids) ids[i] = i;
-        if (node) memcpy(node + (size_t)i * E * 8, ntmp, sizeof(double) * E * 8);
+        if (node) memcpy(node + (size_t)i * E * F, ntmp, sizeof(double) * E * F);
     }
     if (adj) memcpy(adj, v->dist, sizeof(double) * E * E);
 }
@@ -683,7 +841,7 @@ int gmpo_reset(gmpo* h, const uint8_t* mask, double* obs, int32_t* ids, double* 
         if (mask && !mask[n]) continue;
         envv v = view(h, n);
         env_reset(&v, obs ? obs + (size_t)n * A * D : NULL, ids ? ids + (size_t)n * A : NULL,
-                  node ? node + (size_t)n * A * E * 8 : NULL, adj ? adj + (size_t)n * E * E : NULL);
+                  node ? node + (size_t)n * A * E * h->F : NULL, adj ? adj + (size_t)n * E * E : NULL);
     }
     return GMPE_OK;
 }
@@ -749,14 +907,14 @@ static int env_step(envv* v, const int32_t* act, double* obs, int32_t* ids, doub
     double otmp[32], ntmp[GMPE_MAX_ENTITIES * 8], itmp[GMPE_INFO_KEYS], rsum = 0;
     int all_done = 1;
     for (int i = 0; i < A; ++i) {                /* environment.py:1036-1053, IN ORDER */
-        observation(v, i, otmp);
-        const double r = c->scenario == GMPE_SCENARIO_TUBE_JULY ? reward_july(v, i) : reward_nav(v, i);
+        if (c->scenario == GMPE_SCENARIO_ROT_INV) observation_rot(v, i, otmp); else observation(v, i, otmp);
+        const double r = c->scenario == GMPE_SCENARIO_TUBE_JULY ? reward_july(v, i) : (c->scenario == GMPE_SCENARIO_ROT_INV ? reward_rot(v, i) : reward_nav(v, i));
         graph_observation(v, i, ntmp);
         const int dn = v->status[i] || h->current_step[n] >= c->episode_length;   /* _get_done 264-271 */
         info_callback(v, i, r, itmp);
         if (obs) memcpy(obs + (size_t)i * D, otmp, sizeof(double) * D);
         if (ids) ids[i] = i;
-        if (node) memcpy(node + (size_t)i * E * 8, ntmp, sizeof(double) * E * 8);
+        if (node) memcpy(node + (size_t)i * E * h->F, ntmp, sizeof(double) * E * h->F);
         if (rew) rew[i] = r;
         if (done) done[i] = (uint8_t)dn;
         if (info) memcpy(info + (size_t)i * GMPE_INFO_KEYS, itmp, sizeof itmp);
@@ -776,7 +934,7 @@ int gmpo_step(gmpo* h, const int32_t* act, double* obs, int32_t* ids, double* no
     for (int n = 0; n < h->N; ++n) {
         envv v = view(h, n);
         const int r = env_step(&v, act + (size_t)n * A, obs ? obs + (size_t)n * A * D : NULL,
-                               ids ? ids + (size_t)n * A : NULL, node ? node + (size_t)n * A * E * 8 : NULL,
+                               ids ? ids + (size_t)n * A : NULL, node ? node + (size_t)n * A * E * h->F : NULL,
                                adj ? adj + (size_t)n * E * E : NULL, rew ? rew + (size_t)n * A : NULL,
                                done ? done + (size_t)n * A : NULL, info ? info + (size_t)n * A * GMPE_INFO_KEYS : NULL, auto_reset);
         if (did_reset) did_reset[n] = (uint8_t)r;

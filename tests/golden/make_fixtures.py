@@ -3,6 +3,7 @@
     python tests/golden/make_fixtures.py            # writes tests/golden/*.npz
 
 Vectors (data only — inputs and the reference's outputs):
+  rotinv_A{3,6,10}_s{seed}.npz  the same for nav_graph_metered_single_corridor_rot_inv (float32 obs, 7 node features).
   july_A{3,10}_s{seed}.npz   end-to-end rollouts of MultiAgentGraphEnv (July tube scenario, air_taxi),
                              driven like graphworker does (env_wrappers.py:851-873: step, auto-reset
                              when all agents are done), with the uniform-sample tape that replays the
@@ -31,7 +32,7 @@ INFO_KEYS = ["individual_reward", "Dist_to_goal", "Time_req_to_goal", "Num_agent
              "Conformance", "Delta_spacing", "Spacing_violations", "Min_time_to_goal"]
 
 STATE_KEYS = ["x", "y", "theta", "speed", "status", "prev_phase", "phase_reached", "goal_tracker",
-              "p_dist", "time", "current_step"]
+              "p_dist", "time", "current_step", "cooldown", "prev_proj"]
 TUBE_KEYS = ["tube_angle", "entrance", "exit", "tube_e", "tube_n", "tube_L", "half_w", "width",
              "landmarks"]
 
@@ -79,9 +80,11 @@ def _guided_action(w, sc, rng, w_opt, a_opt):
     return np.array(acts)
 
 
-def july_rollout(num_agents, seed, T, world_size=4.0, episode_length=25, guided=False):
+def july_rollout(num_agents, seed, T, world_size=4.0, episode_length=25, guided=False,
+                 scenario_name="nav_metered_one_goal_graph_rotate_tube_july"):
     np.random.seed(seed)
-    args = H.july_args(num_agents, world_size=world_size, episode_length=episode_length)
+    args = H.july_args(num_agents, world_size=world_size, episode_length=episode_length, scenario_name=scenario_name)
+    info_keys = INFO_KEYS + (["Phase_reached"] if "rot_inv" in scenario_name else [])
     with H.UniformTape() as tape:
         env, sc, w = H.make_july_env(args)
         A = num_agents
@@ -120,7 +123,7 @@ def july_rollout(num_agents, seed, T, world_size=4.0, episode_length=25, guided=
             rec["obs"].append(np.array(o)); rec["node"].append(np.array(nd))
             rec["adj"].append(np.array(ad[0])); rec["rew"].append(np.array(rw, dtype=np.float64))
             rec["done"].append(np.array(dn, dtype=bool))
-            rec["info"].append(np.array([[float(info[i][k]) for k in INFO_KEYS] for i in range(A)]))
+            rec["info"].append(np.array([[float(info[i][k]) for k in info_keys] for i in range(A)]))
             rec["edges"].append(pad_edges(w.edge_list, m_max)); rec["n_edges"].append(w.edge_list.shape[1])
             st = H.snapshot(env, sc, w)
             for k in STATE_KEYS:
@@ -149,7 +152,8 @@ def july_rollout(num_agents, seed, T, world_size=4.0, episode_length=25, guided=
         out["st_" + k] = np.array(v)
     for k, v in rrec.items():
         out["rs_" + k] = np.array(v)
-    out["info_keys"] = np.array(INFO_KEYS)
+    out["info_keys"] = np.array(info_keys)
+    out["scenario_name"] = scenario_name
     return out
 
 
@@ -334,6 +338,23 @@ def main():
         print(p, os.path.getsize(p), "resets", int(d["did_reset"].sum()),
               "steps with a done agent", int(d["st_status"].any(axis=1).sum()),
               "max phase", int(d["obs"][:, :, 18].max()), "phase_reached", d["st_phase_reached"].max(axis=0))
+    # rot_inv. The reference crashes at env construction for some seeds (an agent placed inside the
+    # tube before `previous_phase` exists: AttributeError in get_agent_phase, rot_inv.py:712) — such seeds are skipped.
+    ROT = "nav_graph_metered_single_corridor_rot_inv"
+    seed = 5
+    for A, T, ws, el, guided in [(3, 60, 4.0, 25, False), (10, 40, 4.0, 25, False), (3, 130, 2.0, 60, True),
+                                 (3, 130, 2.0, 60, True), (6, 130, 3.0, 70, True), (10, 100, 4.0, 90, True)]:
+        while True:
+            seed += 1
+            try:
+                d = july_rollout(A, seed, T, world_size=ws, episode_length=el, guided=guided, scenario_name=ROT)
+                break
+            except AttributeError as e:
+                print("seed", seed, "reference crashed:", str(e)[:70])
+        p = os.path.join(HERE, "rotinv_A%d_s%d%s.npz" % (A, seed, "_guided" if guided else ""))
+        np.savez_compressed(p, **d)
+        print(p, os.path.getsize(p), "resets", int(d["did_reset"].sum()), "steps with a done agent", int(d["st_status"].any(axis=1).sum()),
+              "max phase", int(d["obs"][:, :, 12].max()), "phase_reached", d["st_phase_reached"].max(axis=0), "cooldown max", d["st_cooldown"].max())
     np.savez_compressed(os.path.join(HERE, "rk45_airtaxi.npz"), **rk45_fixture())
     np.savez_compressed(os.path.join(HERE, "force_classic.npz"), **force_classic_fixture())
     np.savez_compressed(os.path.join(HERE, "force_di.npz"), **force_di_fixture())

@@ -105,9 +105,9 @@ def selfcheck_uniform_patch():
         assert np.array_equal(np.asarray(x), np.asarray(y)), "uniform patch is not bit-identical"
 
 
-def july_args(num_agents=3, world_size=4.0, episode_length=25, **over):
+def july_args(num_agents=3, world_size=4.0, episode_length=25, scenario_name="nav_metered_one_goal_graph_rotate_tube_july", **over):
     """Working arg set of SURVEY.md §8(c)."""
-    d = dict(scenario_name="nav_metered_one_goal_graph_rotate_tube_july", dynamics_type="air_taxi",
+    d = dict(scenario_name=scenario_name, dynamics_type="air_taxi",
              world_size=world_size, num_agents=num_agents, num_landmarks=num_agents,
              num_scripted_agents=0, num_obstacles=0, num_walls=0, collaborative=False, max_speed=2,
              collision_rew=5, formation_rew=1, goal_rew=5, use_dones=False,
@@ -133,7 +133,7 @@ def make_july_env(args):
                              done_callback=scenario.done,
                              id_callback=scenario.get_id,
                              update_graph=scenario.update_graph,
-                             agent_reached_goal_callback=None,
+                             agent_reached_goal_callback=getattr(scenario, "get_agent_reached_goal", None),
                              scenario_name=args.scenario_name,
                              discrete_action=args.discrete_action,
                              dynamics_type=args.dynamics_type)
@@ -151,6 +151,8 @@ def snapshot(env, scenario, world):
         prev_phase=np.array([getattr(a, "previous_phase", 0) for a in ag], dtype=np.int32),
         phase_reached=np.array(scenario.phase_reached, dtype=np.int32),
         goal_tracker=np.array(scenario.goal_tracker, dtype=np.int32),
+        cooldown=np.array(scenario.entry_reward_cooldown, dtype=np.int32),
+        prev_proj=np.array(getattr(scenario, "prev_proj", np.zeros(len(ag))), dtype=np.float64),
         p_dist=np.array([a.state.p_dist for a in ag]), time=np.array([a.state.time for a in ag]),
         current_step=np.int32(env.current_step),
         tube_angle=np.float64(tp["angle"]), entrance=np.array(tp["entrance"]), exit=np.array(tp["exit"]),

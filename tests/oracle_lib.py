@@ -94,7 +94,7 @@ class Oracle(object):
 
     def _bufs(self):
         N, A, E, D = self.N, self.A, self.E, self.D
-        return (np.zeros((N, A, D)), np.zeros((N, A, 1), np.int32), np.zeros((N, A, E, NODE_FEATS)),
+        return (np.zeros((N, A, D)), np.zeros((N, A, 1), np.int32), np.zeros((N, A, E, self.cfg.node_feats)),
                 np.zeros((N, E, E)))
 
     def reset(self, mask=None):
