@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgmpe.so")
 _lib = None
 
-SYMBOLS = ["gmpe_abi_version", "gmpe_last_error", "gmpe_obs_dim", "gmpe_num_entities", "gmpe_create",
+SYMBOLS = ["gmpe_abi_version", "gmpe_last_error", "gmpe_obs_dim", "gmpe_node_feats", "gmpe_num_entities", "gmpe_create",
            "gmpe_destroy", "gmpe_set_rng_tape", "gmpe_reset", "gmpe_step", "gmpe_step_many", "gmpe_step_onehot",
            "gmpe_field_bytes", "gmpe_get_field", "gmpe_set_field", "gmpe_edges_from_adj",
            "gmpe_timing_enable", "gmpe_timing_read", "gmpe_timing_mark", "gmpe_timing_region_ms"]
@@ -38,6 +38,7 @@ def load():
     P, I = C.c_void_p, C.c_int
     lib.gmpe_last_error.restype = C.c_char_p
     lib.gmpe_obs_dim.argtypes = [C.POINTER(GmpeConfig)]
+    lib.gmpe_node_feats.argtypes = [C.POINTER(GmpeConfig)]
     lib.gmpe_num_entities.argtypes = [C.POINTER(GmpeConfig)]
     lib.gmpe_create.argtypes = [C.POINTER(GmpeConfig), I, C.POINTER(P)]
     lib.gmpe_destroy.argtypes = [P]

@@ -44,6 +44,7 @@ struct DevState {
     int32_t *times_required, *dists_to_goal, *dist_left, *goal_reached, *n_agent_coll, *n_obst_coll,
         *spacing_viol, *steps_in_corr, *conformance;
     double *goal_min_time;
+    double *prev_proj;       // [N,A] rot_inv: float32 values held in f64
     double *delta_spacing;   // [N]
     int32_t* error_flags;    // [N]
     const double* tape;      // [N,tape_len] or nullptr
@@ -94,6 +95,40 @@ __device__ __forceinline__ int phase_eval(const double* tube, double px, double 
     if (prev == 2) return 2;
     return 0;
 }
+
+// ---- nav_graph_metered_single_corridor_rot_inv.py geometry (:627-669) and phase FSM (:675-739)
+__device__ __forceinline__ void tube_sy(const double* tube, double px, double py, double& s, double& yy) {
+    const double rx = (double)(float)px - tube[T_ENTX], ry = (double)(float)py - tube[T_ENTY];   // pos rounded to fp32 first
+    s = rx * tube[T_EX] + ry * tube[T_EY];
+    yy = rx * tube[T_NX] + ry * tube[T_NY];
+}
+__device__ __forceinline__ bool in_tube_rect(double s, double y, double L, double hw) { return (-0.05 <= s && s <= L + 0.05) && (fabs(y) <= hw + 0.05); }
+__device__ __forceinline__ bool in_entrance_gate(double s, double y, double L, double hw) {
+    return (-(0.02 * L) - 0.05 <= s && s <= 0.08 * L + 0.05) && (fabs(y) <= hw + 0.05);
+}
+__device__ __forceinline__ bool in_exit_gate(double s, double y, double L, double hw) {
+    return (L - 0.05 * L - 0.05 <= s && s <= L + 0.08 * L + 0.05) && (fabs(y) <= hw + 0.05);
+}
+__device__ __forceinline__ double entrance_gate_distance(double s, double y, double hw) { return hypot(fabs(s), y - clipd(y, -hw, hw)); }
+__device__ __forceinline__ double exit_gate_distance(double s, double y, double L, double hw) {
+    const double ds = (L - s) > 0.0 ? (L - s) : 0.0;
+    return hypot(ds, y - clipd(y, -hw, hw));
+}
+// pure function of (pos, previous_phase, phase_reached); the caller decrements the cooldown (:700-702)
+__device__ __forceinline__ int phase_eval_rot(const double* tube, double px, double py, int prev, int phase_reached) {
+    const double L = tube[T_L], hw = tube[T_HALFW];
+    double s, yy; tube_sy(tube, px, py, s, yy);
+    const bool in_tube = in_tube_rect(s, yy, L, hw), passed = s > L;
+    if (!in_tube && !passed) return 0;
+    if (in_tube) return prev == 0 ? (in_entrance_gate(s, yy, L, hw) ? 1 : 0) : 1;
+    if (phase_reached >= 1) {
+        if (prev == 1 && in_exit_gate(s, yy, L, hw)) return 2;
+        if (prev == 2) return 2;
+    }
+    return 0;
+}
+// get_rotated_position_from_relative (:91-97): [[c, s], [-s, c]] @ v
+__device__ __forceinline__ void rot2(double c, double s, double vx, double vy, double& ox, double& oy) { ox = c * vx + s * vy; oy = -s * vx + c * vy; }
 
 // get_wall_collision_force (core.py:909-964); returns false for None.
 __device__ __forceinline__ bool wall_force(const gmpe_wall& wl, double px, double py, double size, double kf,

@@ -38,7 +38,7 @@ struct KParams {
     const float* onehot;      // [N,A,n_actions] or nullptr
     const uint8_t* mask;      // reset mask or nullptr
     int mode;
-    int A, L, O, E, D;
+    int A, L, O, E, D, F;     // F = node features per row (8, rot_inv: 7)
     int G;                    // envs per workgroup (G*A <= 64)
     int spec;                 // 1: multi-wave tiles specialise (wave 0 reward/info, waves 1.. graph stores)
     int nt;                   // 1: nontemporal graph stores (outputs per launch exceed the 256 MiB Infinity Cache)
@@ -60,6 +60,7 @@ struct Lds {
     double *n2, *n3;                  // [G][A]  ... AFTER it (reset_velocity on goal reach)
     double *vox, *voy, *vnx, *vny;    // [G][A]  p_vel before / after
     double *serr;                     // [G][A]  spacing error of this step (…_july.py:1168-1180)
+    double *cn, *sn;                  // [G][A]  cos / sin of the post-reward heading (rot_inv node features)
     double *rew;                      // [G][A]
     double *tube;                     // [G][12]
     double *Dm;                       // [G][A][E] fp64 agent->entity distances (rows of cached_dist_mag)
@@ -73,7 +74,7 @@ struct Lds {
 };
 __host__ __device__ inline size_t lds_bytes(int G, int A, int E, int D) {
     const size_t EE4 = ((size_t)E * E + 3) / 4 * 4, AD4 = ((size_t)A * D + 3) / 4 * 4;
-    size_t d = (size_t)G * (2 * E + 10 * A + 12 + (size_t)A * E);   // doubles
+    size_t d = (size_t)G * (2 * E + 12 * A + 12 + (size_t)A * E);   // doubles
     size_t f = (size_t)G * (EE4 + AD4);                             // floats
     size_t i = (size_t)G * (9 * A + 4 + E) + (size_t)A * (A - 1) / 2 + 1;   // ints
     return d * 8 + 16 + f * 4 + ((i * 4 + 15) / 16) * 16 + 32;
@@ -84,7 +85,7 @@ __device__ inline Lds carve(char* base, int G, int A, int E, int D) {
     l.ex = d; d += G * E; l.ey = d; d += G * E;
     l.s2 = d; d += G * A; l.s3 = d; d += G * A; l.n2 = d; d += G * A; l.n3 = d; d += G * A;
     l.vox = d; d += G * A; l.voy = d; d += G * A; l.vnx = d; d += G * A; l.vny = d; d += G * A;
-    l.serr = d; d += G * A; l.rew = d; d += G * A; l.tube = d; d += G * 12;
+    l.serr = d; d += G * A; l.cn = d; d += G * A; l.sn = d; d += G * A; l.rew = d; d += G * A; l.tube = d; d += G * 12;
     l.Dm = d; d += (size_t)G * A * E;
     if ((uintptr_t)d & 15) d += 1;
     float* f = reinterpret_cast<float*>(d);
@@ -104,7 +105,7 @@ __device__ inline Lds env_view(const Lds& l, int g, int A, int E, int D) {
     v.ex = l.ex + g * E; v.ey = l.ey + g * E;
     v.s2 = l.s2 + g * A; v.s3 = l.s3 + g * A; v.n2 = l.n2 + g * A; v.n3 = l.n3 + g * A;
     v.vox = l.vox + g * A; v.voy = l.voy + g * A; v.vnx = l.vnx + g * A; v.vny = l.vny + g * A;
-    v.serr = l.serr + g * A; v.rew = l.rew + g * A; v.tube = l.tube + g * 12;
+    v.serr = l.serr + g * A; v.cn = l.cn + g * A; v.sn = l.sn + g * A; v.rew = l.rew + g * A; v.tube = l.tube + g * 12;
     v.Dm = l.Dm + (size_t)g * A * E;
     v.s_old = l.s_old + g * A; v.newf = l.newf + g * A; v.gt = l.gt + g * A;
     v.dtg_o = l.dtg_o + g * A; v.dtg_n = l.dtg_n + g * A; v.trq_o = l.trq_o + g * A; v.trq_n = l.trq_n + g * A;
@@ -216,6 +217,35 @@ __device__ __forceinline__ void write_obs(const KParams& p, const Lds& l, int i,
     }
 }
 
+// Scenario.observation of rot_inv (…rot_inv.py:1453-1548): 13 float32 = [cos th, sin th, speed, goal (rotated), two nearest
+// neighbours (rel. vector cast to float32, then rotated in float64), s/L, y/half_w (clipped), exit-gate distance / L, phase].
+// Uses the PRE-reward heading (the reward of this agent runs after its observation).
+template <int AP>
+__device__ __forceinline__ void write_obs_rot(const KParams& p, const Lds& l, int i, int phase) {
+    float* o = l.obs + (size_t)i * p.D;
+    const double px = l.ex[i], py = l.ey[i], th = l.s2[i];
+    double sn, cs; sincos(th, &sn, &cs);
+    const double INF = __builtin_huge_val();
+    int b1 = -1, b2 = -1; double d1 = INF, d2 = INF;
+    const double* row = l.Dm + (size_t)i * p.E;
+    for (int k = 0; k < p.A; ++k) {
+        const double d = k != i ? row[k] : INF;
+        const bool lt1 = d < d1, lt2 = d < d2;
+        d2 = lt1 ? d1 : (lt2 ? d : d2); b2 = lt1 ? b1 : (lt2 ? k : b2);
+        d1 = lt1 ? d : d1; b1 = lt1 ? k : b1;
+    }
+    double gx, gy; rot2(cs, sn, l.ex[p.A + i] - px, l.ey[p.A + i] - py, gx, gy);
+    double n1x = 0, n1y = 0, n2x = 0, n2y = 0;
+    if (b1 >= 0) rot2(cs, sn, (double)(float)(l.ex[b1] - px), (double)(float)(l.ey[b1] - py), n1x, n1y);
+    if (b2 >= 0) rot2(cs, sn, (double)(float)(l.ex[b2] - px), (double)(float)(l.ey[b2] - py), n2x, n2y);
+    const double L = l.tube[T_L], hw = l.tube[T_HALFW];
+    double s, yy; tube_sy(l.tube, px, py, s, yy);
+    o[0] = (float)cs; o[1] = (float)sn; o[2] = (float)l.s3[i];
+    o[3] = (float)gx; o[4] = (float)gy; o[5] = (float)n1x; o[6] = (float)n1y; o[7] = (float)n2x; o[8] = (float)n2y;
+    o[9] = (float)clipd(s / L, -2.0, 2.0); o[10] = (float)clipd(yy / (hw + 1e-9), -2.0, 2.0);
+    o[11] = (float)(exit_gate_distance(s, yy, L, hw) / (L + 1e-9)); o[12] = (float)phase;
+}
+
 // Serial reset of one env by ONE lane (reset_world: …_july.py:339-420, 440-515, 518-613,
 // custom_scenarios/utils.py:165-193; navigation_graph: DESIGN.md). Writes positions / headings to
 // LDS (ex, ey, n2, n3, tube) and landmark / obstacle / tube records to HBM. Bounded rejection loop.
@@ -223,7 +253,7 @@ __device__ __forceinline__ void reset_world_serial(const KParams& p, const Lds& 
     const gmpe_config& c = p.c;
     const double ws = c.world_size, size = c.entity_size;
     const int A = p.A, L = p.L, O = p.O;
-    if (c.scenario == GMPE_SCENARIO_TUBE_JULY) {
+    if (c.scenario != GMPE_SCENARIO_NAVIGATION_GRAPH) {
         (void)draw_at(c, p.s, n, ctr++, err);                              // wall_length draw, unused (:368)
         const double a = 3 * size * 2.5, b = ws * 0.15;
         const double width = a > b ? a : b;
@@ -244,8 +274,10 @@ __device__ __forceinline__ void reset_world_serial(const KParams& p, const Lds& 
         int k = 0, tries = 0;
         while (k < A) {
             const double u0 = draw_at(c, p.s, n, ctr++, err), u1 = draw_at(c, p.s, n, ctr++, err);
-            const double jx = 0.2 * (-ws + (ws - (-ws)) * u0), jy = 0.2 * (-ws + (ws - (-ws)) * u1);
-            const double dfe = (ws + k) / 5;
+            const bool rot = c.scenario == GMPE_SCENARIO_ROT_INV;              // rot_inv.py:463, 469
+            const double jf = rot ? 0.3 : 0.2;
+            const double jx = jf * (-ws + (ws - (-ws)) * u0), jy = jf * (-ws + (ws - (-ws)) * u1);
+            const double dfe = rot ? (ws + k) / 3 : (ws + k) / 5;
             const double px = entx + dfe * sa + jx, py = enty + dfe * ca + jy;
             bool bad = obstacle_collision(p, l, px, py, size);
             for (int q = 0; q < k && !bad; ++q) bad = norm2(l.ex[q] - px, l.ey[q] - py) < c.sep_dist;
@@ -414,7 +446,42 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, 
         }
     }
     
-    if (p.o.node_obs && !(abl & 2)) {
+    if (p.o.node_obs && !(abl & 2) && p.F == 7) {
+        // rot_inv node row (…rot_inv.py:1690-1766): 7 float32 = [rel_vel, rel_pos, rel_goal (all rotated by the ego heading), type].
+        // Positions / velocities are rounded to float32 FIRST, differenced in float32, rotated in float64, rounded again.
+        // A lane owns one (env, entity) and walks the egos; rows are 28 B, so the stores are scalar.
+        float* base = p.o.node_obs + (size_t)n0 * A * E * 7;
+        for (int sidx = t0; sidx < Gv * E; sidx += nthr) {
+            const int gg = fdiv(sidx, E, p.m_E), k = sidx - gg * E;
+            if (!l.flags[gg * 4 + 3]) continue;
+            const int ab = gg * A, eb = gg * E;
+            const bool kag = k < A;
+            const int kk = kag ? k : 0;
+            const float kx = (float)l.ex[eb + k], ky = (float)l.ey[eb + k];
+            const float kvox = kag ? (float)l.vox[ab + kk] : 0.0f, kvoy = kag ? (float)l.voy[ab + kk] : 0.0f;
+            const float kvnx = kag ? (float)l.vnx[ab + kk] : 0.0f, kvny = kag ? (float)l.vny[ab + kk] : 0.0f;
+            const bool knew = kag && l.newf[ab + kk] != 0;
+            const float gxk = kag ? (float)l.ex[eb + A + kk] : 0.0f, gyk = kag ? (float)l.ey[eb + A + kk] : 0.0f;
+            const float typ = kag ? 0.0f : (k < A + L ? 1.0f : 2.0f);
+            for (int ei = 0; ei < A; ++ei) {
+                const float apx = (float)l.ex[eb + ei], apy = (float)l.ey[eb + ei];
+                const bool en = l.newf[ab + ei] != 0;
+                const float avx = (float)(en ? l.vnx[ab + ei] : l.vox[ab + ei]), avy = (float)(en ? l.vny[ab + ei] : l.voy[ab + ei]);
+                const double cs = l.cn[ab + ei], sn = l.sn[ab + ei];          // ego heading AFTER its own reward
+                const bool post = knew && k <= ei;
+                const float rvx = (post ? kvnx : kvox) - avx, rvy = (post ? kvny : kvoy) - avy;
+                const float rpx = kx - apx, rpy = ky - apy;
+                double o0, o1, o2, o3, o4, o5;
+                rot2(cs, sn, (double)rvx, (double)rvy, o0, o1);
+                rot2(cs, sn, (double)rpx, (double)rpy, o2, o3);
+                if (kag) rot2(cs, sn, (double)(gxk - apx), (double)(gyk - apy), o4, o5); else { o4 = o2; o5 = o3; }
+                float* dst = base + ((size_t)(gg * A + ei) * E + k) * 7;
+                dst[0] = (float)o0; dst[1] = (float)o1; dst[2] = (float)o2; dst[3] = (float)o3;
+                dst[4] = (float)o4; dst[5] = (float)o5; dst[6] = typ;
+            }
+        }
+    }
+    if (p.o.node_obs && !(abl & 2) && p.F != 7) {
         // node row (ego, entity k) = 2 float4: [rel_vel, rel_pos] and [rel_goal, occupied, type].
         // A lane owns one (env, entity, half) slot, keeps that entity's data in registers and walks the egos.
         float4* base = reinterpret_cast<float4*>(p.o.node_obs + (size_t)n0 * A * E * GMPE_NODE_FEATS);
@@ -481,6 +548,7 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
     const int n0 = blockIdx.x * G;
     const int Gv = min(G, N - n0);                                      // envs actually present in this tile
     const bool july = c.scenario == GMPE_SCENARIO_TUBE_JULY;
+    const bool rotinv = c.scenario == GMPE_SCENARIO_ROT_INV;
     const bool step = p.mode == MODE_STEP;
     const bool kin = kinematic(c);
     const int EE = E * E, EE4 = (EE + 3) / 4 * 4, AD4 = (A * D + 3) / 4 * 4;
@@ -499,7 +567,7 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
     int prev_phase = 0, phase_reached = 0, cooldown = 0;
     double p_dist = 0, tim = 0;
     int trq = -1, dtg = -1, dleft = -1, greached = -1, nac = 0, noc = 0, sv = 0, sic = 0, conf = 0;
-    double gmt = 0, dsp0 = 0;
+    double gmt = 0, dsp0 = 0, pproj = 0;
     int cur_step = 0, act_idx = 0;
     int err = 0;
     int64_t ctr0 = 0;
@@ -526,6 +594,7 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
             greached = p.s.goal_reached[na]; nac = p.s.n_agent_coll[na]; noc = p.s.n_obst_coll[na];
             sv = p.s.spacing_viol[na]; sic = p.s.steps_in_corr[na]; conf = p.s.conformance[na];
             gmt = p.s.goal_min_time[na];
+            if (rotinv) pproj = p.s.prev_proj[na];
             dsp0 = p.s.delta_spacing[n];
             if (p.act) act_idx = p.act[na];
             else {                                                      // np.argmax: first maximum
@@ -676,6 +745,14 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
                 if (cooldown > 0) cooldown -= 1;
                 prevA = prevB;
                 goal_branch = (cp == 2 && phase_reached != 0);
+            } else if (rotinv) {
+                // rot_inv.py:675-739: the query mutates only the cooldown, so observation's and reward's calls agree;
+                // phase 2 is only returned with phase_reached >= 1, hence the goal block runs iff cp == 2 (:1281-1297)
+                ph1 = phase_eval_rot(v.tube, px, py, prev_phase, phase_reached);
+                if (cooldown > 0) cooldown -= 1;
+                if (cooldown > 0) cooldown -= 1;
+                cp = ph1;
+                goal_branch = (cp == 2);
             }
             dgoal = v.Dm[(size_t)i * E + A + i];
             v.newf[i] = goal_branch && dgoal < c.goal_thresh && !v.s_old[i];
@@ -692,6 +769,7 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
                     double vx, vy; vel_of(c, v.n2[i], v.n3[i], vx, vy);
                     v.vnx[i] = vx; v.vny[i] = vy;
                 } else { v.n2[i] = v.s2[i]; v.n3[i] = v.s3[i]; v.vnx[i] = v.vox[i]; v.vny[i] = v.voy[i]; }
+                if (rotinv) { double sn_, cn_; sincos(v.n2[i], &sn_, &cn_); v.cn[i] = cn_; v.sn[i] = sn_; }
                 if (i == 0) v.flags[1] = kin ? __popcll(bal & emask) : 0;   // draws consumed (DI reset_velocity draws none)
                 // done flag (_get_done environment.py:264-271) and this step's adjacency mask (…_july.py:1627-1648:
                 // done agents, reached landmarks) depend only on status / goal_tracker: known before the rewards
@@ -744,7 +822,7 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
             if (ag) {
                 const double px = v.ex[i], py = v.ey[i];
                 const double* row = v.Dm + (size_t)i * E;
-                write_obs<AP>(p, v, i, v.vox[i], v.voy[i], ph1);
+                if (rotinv) write_obs_rot<AP>(p, v, i, ph1); else write_obs<AP>(p, v, i, v.vox[i], v.voy[i], ph1);
                 STAMP(13);
                 // collision block (…_july.py:1117-1124) and info_callback's collision count (:780-786) in one sweep
                 int ncol_r = 0, ncol_i = 0;
@@ -815,12 +893,59 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
                     if (cp < prevA) rew -= c.collision_rew * 3;
                     if (cp < phase_reached) rew -= c.collision_rew;
                     prev_phase = cp;
+                } else if (rotinv) {
+                    // Scenario.reward, rot_inv.py:1122-1338
+                    const double Lt = v.tube[T_L], hw = v.tube[T_HALFW];
+                    double ts, ty; tube_sy(v.tube, px, py, ts, ty);
+                    if (cp == 2 && cp > prev_phase + 1) rew -= c.goal_rew;
+                    if (cp == prev_phase + 1 && phase_reached == cp - 1) {
+                        if (cp == 1 && in_entrance_gate(ts, ty, Lt, hw) && cooldown == 0) {
+                            rew += c.goal_rew;
+                            cooldown = (int)((double)c.episode_length / 10);       // float into an int32 array (:1200, :228)
+                            phase_reached = 1;
+                        } else if (cp == 2) { rew += c.goal_rew; phase_reached = 2; }
+                    }
+                    if (cp == 0) rew -= entrance_gate_distance(ts, ty, hw);
+                    else if (cp == 1) {
+                        const double tdx = v.tube[T_EXX] - v.tube[T_ENTX], tdy = v.tube[T_EXY] - v.tube[T_ENTY];
+                        const double tlen = sqrt(tdx * tdx + tdy * tdy);
+                        const double proj = (px - v.tube[T_ENTX]) * (tdx / tlen) + (py - v.tube[T_ENTY]) * (tdy / tlen);
+                        double hx, hy; sincos(v.s2[i], &hy, &hx);
+                        int front = -1, back = -1; double fproj = 0, bproj = 0;
+                        for (int k = 0; k < A; ++k) {
+                            if (k == i) continue;
+                            const double pj = (v.ex[k] - px) * hx + (v.ey[k] - py) * hy;
+                            if (pj > 0) { if (front < 0 || pj < fproj) { front = k; fproj = pj; } }
+                            else { if (back < 0 || pj > bproj) { back = k; bproj = pj; } }
+                        }
+                        if (front >= 0) { const double df = row[front] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
+                        if (back >= 0) { const double df = row[back] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
+                        if (serr > 0) sv += 1;
+                        rew -= serr * c.formation_rew;
+                        rew -= exit_gate_distance(ts, ty, Lt, hw);
+                        const double gain = c.goal_rew / (c.world_size * 0.8 * 10);             // :522
+                        const double dproj = proj - pproj;
+                        rew += gain * (dproj > -0.05 ? dproj : -0.05);
+                        sic += 1;
+                        pproj = (double)(float)proj;                                           // float32 array (:374)
+                    } else if (cp == 2 && phase_reached == 0) cp = 0;
+                    else if (cp == 2) {
+                        if (dgoal < c.goal_thresh) { if (me_new) rew += c.goal_rew * 5; }
+                        else rew -= dgoal;
+                    }
+                    if (phase_reached == 1 && cp == 0) conf += 1;
+                    if (cp > phase_reached) phase_reached = cp;
+                    if (cp < prev_phase) rew -= c.collision_rew;
+                    if (cp < phase_reached) rew -= c.collision_rew;
+                    prev_phase = cp;
+                    if (in_tube_rect(ts, ty, Lt, hw) && cp != 1) rew -= c.collision_rew;
+                    if (ts > Lt && phase_reached < 1) rew -= c.goal_rew;
                 } else {
                     if (dgoal < c.goal_thresh) { if (me_new) rew += c.goal_rew * 5; }
                     else rew -= dgoal;
                 }
                 rew = clipd(rew, -4 * c.collision_rew, c.goal_rew * 5);
-                rew = clipd(rew, c.min_reward, c.max_reward);
+                if (!rotinv) rew = clipd(rew, c.min_reward, c.max_reward);                      // rot_inv.py:1338 clips once
                 v.serr[i] = serr; v.rew[i] = rew;
 
                 STAMP(15);
@@ -865,7 +990,7 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
                         ssv += ok ? (nw ? svn : svo) : 0;
                     }
                     double dsp = dsp0;
-                    if (july) for (int a = 0; a <= i; ++a) dsp += v.serr[a];   // same order as the list append (:1180)
+                    if (july || rotinv) for (int a = 0; a <= i; ++a) dsp += v.serr[a];   // same order as the list append (:1180)
                     const double dm = sd / A, tm = st / A;
                     // population variance = (A*sum(x^2) - sum(x)^2) / A^2, numerator exact
                     const double dvn = (double)A * sdd - sd * sd, tvn = (double)A * stt - st * st;
@@ -878,11 +1003,12 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
                     o[14] = (float)(dsp / (ssv != 0 ? (double)ssv : 1.0));
                     o[15] = (float)((double)sv / (sic != 0 ? sic : 1));
                     o[16] = (float)gmt;
+                    o[17] = (float)phase_reached;
                 }
                 if (!all_done) {                                            // persist the stepped state
                     if (i == 0) {
                         double dsp = dsp0;
-                        if (july) for (int a = 0; a < A; ++a) dsp += v.serr[a];
+                        if (july || rotinv) for (int a = 0; a < A; ++a) dsp += v.serr[a];
                         p.s.delta_spacing[n] = dsp;
                         p.s.rng_ctr[n] = ctr0 + v.flags[1];
                         p.s.current_step[n] = cur_step;
@@ -894,6 +1020,7 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
                     p.s.times_required[na] = trq; p.s.dists_to_goal[na] = dtg; p.s.dist_left[na] = dleft;
                     p.s.goal_reached[na] = greached; p.s.n_agent_coll[na] = nac; p.s.n_obst_coll[na] = noc;
                     p.s.spacing_viol[na] = sv; p.s.steps_in_corr[na] = sic; p.s.conformance[na] = conf;
+                    if (rotinv) p.s.prev_proj[na] = pproj;
                 }
             }
             STAMP(7);
@@ -933,6 +1060,7 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
                 int prevA = prev_phase, ph = 0;
                 if (july) ph = phase_eval(v.tube, v.ex[i], v.ey[i], prev_phase, prevA);   // reset-time observation (:1447)
                 prev_phase = prevA;
+                if (rotinv) { ph = phase_eval_rot(v.tube, v.ex[i], v.ey[i], prev_phase, 0); double sn_, cn_; sincos(v.n2[i], &sn_, &cn_); v.cn[i] = cn_; v.sn[i] = sn_; p.s.prev_proj[na] = 0.0; }
                 const double dx = v.ex[i] - v.ex[A + i], dy = v.ey[i] - v.ey[A + i];
                 gmt = c.max_speed > 0 ? sqrt(dx * dx + dy * dy) / c.max_speed : 0.0;
                 p.s.x[na] = v.ex[i]; p.s.y[na] = v.ey[i]; p.s.s2[na] = v.n2[i]; p.s.s3[na] = v.n3[i];
@@ -948,7 +1076,7 @@ __global__ __launch_bounds__(BLOCK, (WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOW
             distance_pass<BLOCK>(p, l, Gv, tid, true);
             static_block<BLOCK>(p, l, Gv, tid, true);
             __syncthreads();
-            if (mine) write_obs<AP>(p, v, i, v.vox[i], v.voy[i], ph1);
+            if (mine) { if (rotinv) write_obs_rot<AP>(p, v, i, ph1); else write_obs<AP>(p, v, i, v.vox[i], v.voy[i], ph1); }
             any_mask = 0;
             for (int gg = 0; gg < Gv; ++gg) any_mask |= l.flags[gg * 4 + 2];
         }
@@ -1048,7 +1176,7 @@ struct gmpe_handle {
     gmpe_config c;
     int device;
     DevState s;
-    int A, L, O, E, D;
+    int A, L, O, E, D, F;
     std::vector<void*> allocs;
     bool timing = false;
     std::vector<hipEvent_t> ev;      // pairs
@@ -1084,6 +1212,7 @@ extern "C" {
 int gmpe_abi_version(void) { return GMPE_ABI_VERSION; }
 const char* gmpe_last_error(void) { return g_err.c_str(); }
 int gmpe_obs_dim(const gmpe_config* c) { return c->scenario == GMPE_SCENARIO_TUBE_JULY ? 19 : 13; }
+int gmpe_node_feats(const gmpe_config* c) { return c->scenario == GMPE_SCENARIO_ROT_INV ? 7 : GMPE_NODE_FEATS; }
 int gmpe_num_entities(const gmpe_config* c) { return c->num_agents + c->num_landmarks + c->num_obstacles; }
 
 static int field_info(const gmpe_handle* h, int f, void** ptr, size_t* bytes) {
@@ -1118,6 +1247,7 @@ static int field_info(const gmpe_handle* h, int f, void** ptr, size_t* bytes) {
         case GMPE_F_GOAL_MIN_TIME: *ptr = s.goal_min_time; *bytes = NA * 8; break;
         case GMPE_F_DELTA_SPACING: *ptr = s.delta_spacing; *bytes = N * 8; break;
         case GMPE_F_ERROR_FLAGS: *ptr = s.error_flags; *bytes = N * 4; break;
+        case GMPE_F_PREV_PROJ: *ptr = s.prev_proj; *bytes = NA * 8; break;
         default: return fail(GMPE_ERR_INVALID_ARG, "unknown field id");
     }
     return GMPE_OK;
@@ -1130,10 +1260,10 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     if (cfg->num_envs < 1 || cfg->num_agents < 1 || cfg->num_agents > GMPE_MAX_AGENTS || cfg->num_landmarks < cfg->num_agents ||
         cfg->num_obstacles < 0 || cfg->num_walls < 0 || cfg->num_walls > GMPE_MAX_WALLS || E > GMPE_MAX_ENTITIES)
         return fail(GMPE_ERR_INVALID_ARG, "config out of range (agents<=64, entities<=160, walls<=8, landmarks>=agents)");
-    if (cfg->scenario != GMPE_SCENARIO_NAVIGATION_GRAPH && cfg->scenario != GMPE_SCENARIO_TUBE_JULY)
+    if (cfg->scenario != GMPE_SCENARIO_NAVIGATION_GRAPH && cfg->scenario != GMPE_SCENARIO_TUBE_JULY && cfg->scenario != GMPE_SCENARIO_ROT_INV)
         return fail(GMPE_ERR_UNSUPPORTED, "unknown scenario");
-    if ((cfg->scenario == GMPE_SCENARIO_TUBE_JULY) == (cfg->dynamics == GMPE_DYN_DOUBLE_INTEGRATOR))
-        return fail(GMPE_ERR_UNSUPPORTED, "tube_july is kinematic; navigation_graph is double_integrator");
+    if ((cfg->scenario != GMPE_SCENARIO_NAVIGATION_GRAPH) == (cfg->dynamics == GMPE_DYN_DOUBLE_INTEGRATOR))
+        return fail(GMPE_ERR_UNSUPPORTED, "the tube scenarios are kinematic; navigation_graph is double_integrator");
     if (cfg->dynamics == GMPE_DYN_DOUBLE_INTEGRATOR ? (cfg->n_actions != 5 && cfg->n_actions != 9) : cfg->n_actions != 25)
         return fail(GMPE_ERR_INVALID_ARG, "n_actions does not match the dynamics");
     int ndev = 0;
@@ -1142,7 +1272,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     HIPCHK(hipSetDevice(device));
     gmpe_handle* h = new gmpe_handle();
     h->c = *cfg; h->device = device;
-    h->A = cfg->num_agents; h->L = cfg->num_landmarks; h->O = cfg->num_obstacles; h->E = E; h->D = gmpe_obs_dim(cfg);
+    h->A = cfg->num_agents; h->L = cfg->num_landmarks; h->O = cfg->num_obstacles; h->E = E; h->D = gmpe_obs_dim(cfg); h->F = gmpe_node_feats(cfg);
     const size_t N = cfg->num_envs, NA = N * h->A;
     DevState& s = h->s;
     std::vector<std::pair<size_t, std::pair<size_t, int>>> fills;
@@ -1157,7 +1287,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
         AL(s.tube, N * GMPE_TUBE_STRIDE, 0) AL(s.landmarks, N * h->L * 2, 0) AL(s.obstacles, N * h->O * 2, 0)
         AL(s.times_required, NA, 0xFF) AL(s.dists_to_goal, NA, 0xFF) AL(s.dist_left, NA, 0xFF) AL(s.goal_reached, NA, 0xFF)
         AL(s.n_agent_coll, NA, 0) AL(s.n_obst_coll, NA, 0) AL(s.spacing_viol, NA, 0) AL(s.steps_in_corr, NA, 0)
-        AL(s.conformance, NA, 0) AL(s.goal_min_time, NA, 0) AL(s.delta_spacing, N, 0) AL(s.error_flags, N, 0)
+        AL(s.conformance, NA, 0) AL(s.goal_min_time, NA, 0) AL(s.delta_spacing, N, 0) AL(s.error_flags, N, 0) AL(s.prev_proj, NA, 0)
 #undef AL
         if (pass == 0) {
             void* q = nullptr;
@@ -1289,7 +1419,7 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
     p.c = h->c; p.s = h->s;
     if (out) p.o = *out;
     p.act = act; p.onehot = onehot; p.mask = mask; p.mode = mode;
-    p.A = h->A; p.L = h->L; p.O = h->O; p.E = h->E; p.D = h->D; p.G = h->G;
+    p.A = h->A; p.L = h->L; p.O = h->O; p.E = h->E; p.D = h->D; p.F = h->F; p.G = h->G;
     p.ablate = h->ablate;
     p.nt = h->nt;
     p.spec = h->spec;

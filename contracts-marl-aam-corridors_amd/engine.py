@@ -40,7 +40,7 @@ class GmpeEngine(object):
         self.out = StepOutputs(
             obs=torch.empty((N, A, D), dtype=torch.float32, device=dev),
             agent_id=torch.empty((N, A, 1), dtype=torch.int32, device=dev),
-            node_obs=torch.empty((N, A, E, NODE_FEATS), dtype=torch.float32, device=dev),
+            node_obs=torch.empty((N, A, E, cfg.node_feats), dtype=torch.float32, device=dev),
             adj=torch.empty((N, E, E) if adj_compact else (N, A, E, E), dtype=torch.float32, device=dev),
             reward=torch.empty((N, A), dtype=torch.float32, device=dev),
             done=torch.empty((N, A), dtype=torch.uint8, device=dev),

@@ -24,7 +24,7 @@ class DeviceRolloutBuffer(object):
         T1 = self.T + 1
         f32, i32 = torch.float32, torch.int32
         self.obs = torch.zeros((T1, N, A, D), dtype=f32, device=dev)
-        self.node_obs = torch.zeros((T1, N, A, E, NODE_FEATS), dtype=f32, device=dev)
+        self.node_obs = torch.zeros((T1, N, A, E, c.node_feats), dtype=f32, device=dev)
         adj_shape = (T1, N, E, E) if engine.adj_compact else (T1, N, A, E, E)
         self._adj = torch.zeros(adj_shape, dtype=f32, device=dev)
         self.agent_id = torch.zeros((T1, N, A, 1), dtype=i32, device=dev)

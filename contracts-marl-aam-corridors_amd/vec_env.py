@@ -24,11 +24,13 @@ class LazyInfos(object):
     keys every step would dominate the host, so the dicts are created on first access.
     """
 
-    def __init__(self, info_dev, n_envs, n_agents, include_min_time=True):
+    def __init__(self, info_dev, n_envs, n_agents, include_min_time=True, include_phase=False):
         self._dev = info_dev
         self._host = None
         self._n, self._a = n_envs, n_agents
-        self._keys = INFO_KEYS if include_min_time else INFO_KEYS[:-1]
+        # (key, column) pairs: 'Min_time_to_goal' only with max_speed (…_july.py:826-828), 'Phase_reached' only in rot_inv (:835)
+        self._keys = [(k, j) for j, k in enumerate(INFO_KEYS)
+                      if (k != "Min_time_to_goal" or include_min_time) and (k != "Phase_reached" or include_phase)]
 
     def _fetch(self):
         if self._host is None:
@@ -47,14 +49,14 @@ class LazyInfos(object):
         if not 0 <= e < self._n:
             raise IndexError(e)
         h = self._fetch()
-        return [dict(zip(self._keys, h[e, a, :len(self._keys)].tolist())) for a in range(self._a)]
+        return [{k: float(h[e, a, j]) for k, j in self._keys} for a in range(self._a)]
 
     def __iter__(self):
         for e in range(self._n):
             yield self[e]
 
     def as_array(self):
-        """[N, A, 17] float64 in config.INFO_KEYS order (no dict construction)."""
+        """[N, A, 18] float64 in config.INFO_KEYS order (no dict construction)."""
         return self._fetch()
 
 
@@ -79,7 +81,7 @@ class BatchedGraphMPEVecEnv(object):
         self.observation_space = [Box(-np.inf, np.inf, (D,), f32) for _ in range(A)]
         self.share_observation_space = [Box(-np.inf, np.inf, (A * D,), f32) for _ in range(A)]
         self.action_space = [Discrete(c.n_actions) for _ in range(A)]
-        self.node_observation_space = [Box(-np.inf, np.inf, (E, NODE_FEATS), f32) for _ in range(A)]
+        self.node_observation_space = [Box(-np.inf, np.inf, (E, self.cfg.node_feats), f32) for _ in range(A)]
         self.adj_observation_space = [Box(-np.inf, np.inf, (E, E), f32) for _ in range(A)]
         self.edge_observation_space = [Box(-np.inf, np.inf, (1,), f32) for _ in range(A)]
         self.agent_id_observation_space = [Box(-np.inf, np.inf, (1,), f32) for _ in range(A)]
@@ -158,7 +160,8 @@ class BatchedGraphMPEVecEnv(object):
         self._pending, self.waiting = None, False
         obs, ids, node, adj, rew, done = self._fetch(o, True)    # synchronises the stream
         done = done.astype(bool)
-        infos = LazyInfos(o.info.clone(), self.num_envs, self.num_agents, include_min_time=self.cfg.max_speed > 0)
+        infos = LazyInfos(o.info.clone(), self.num_envs, self.num_agents, include_min_time=self.cfg.max_speed > 0,
+                          include_phase=self.cfg.node_feats == 7)
         return obs, ids, node, adj, rew, done, infos
 
     def step(self, actions, num_current_episode=None):

@@ -16,7 +16,8 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-JULY = sorted(glob.glob(os.path.join(GOLD, "july_A*_s*.npz")))
+JULY = sorted(glob.glob(os.path.join(GOLD, "july_A*_s*.npz"))) + sorted(glob.glob(os.path.join(GOLD, "rotinv_A*_s*.npz")))
+ROT = "nav_graph_metered_single_corridor_rot_inv"
 TOL = 1e-5
 
 
@@ -37,8 +38,8 @@ def edges_numpy(adj32, d, inclusive=False):
     return np.stack([b * E + r, b * E + c]).astype(np.int32), adj32[b, r, c]
 
 
-def _july_cfg(d, **kw):
-    return gmpe.make_config(scenario_name="nav_metered_one_goal_graph_rotate_tube_july",
+def _july_cfg(d, scenario_name="nav_metered_one_goal_graph_rotate_tube_july", **kw):
+    return gmpe.make_config(scenario_name=scenario_name,
                             num_envs=1, num_agents=int(d["A"]), world_size=float(d["world_size"]),
                             episode_length=int(d["episode_length"]), max_speed=float(d["max_speed"]),
                             collision_rew=float(d["collision_rew"]), formation_rew=float(d["formation_rew"]),
@@ -50,7 +51,9 @@ def test_golden_replay_on_gpu(path):
     """The reference's own rollouts (incl. its np.random draws via the tape) replayed on the GPU."""
     d = np.load(path)
     A, E, T = int(d["A"]), int(d["E"]), int(d["T"])
-    eng = _engine(_july_cfg(d))
+    rot = os.path.basename(path).startswith("rotinv")
+    eng = _engine(_july_cfg(d, ROT) if rot else _july_cfg(d))
+    assert _np(eng.out.node_obs).shape[-1] == (7 if rot else 8)
     eng.set("prev_phase", d["init_prev_phase"][None])
     eng.set_tape(d["tape"][None])
     o = eng.reset()
@@ -78,8 +81,12 @@ def test_golden_replay_on_gpu(path):
         adj = _np(o.adj)[0]
         np.testing.assert_allclose(adj, np.broadcast_to(d["ret_adj"][t], (A, E, E)), rtol=0, atol=TOL, err_msg="adj t=%d" % t)
         np.testing.assert_array_equal(adj == 0, np.broadcast_to(d["ret_adj"][t] == 0, (A, E, E)))
-        np.testing.assert_allclose(_np(o.info)[0], d["info"][t], rtol=2e-6, atol=2e-5, err_msg="info t=%d" % t)
+        K = d["info"].shape[-1]                       # 17 keys in the July file, 18 (+Phase_reached) in rot_inv
+        np.testing.assert_allclose(_np(o.info)[0][:, :K], d["info"][t], rtol=2e-6, atol=2e-5, err_msg="info t=%d" % t)
         if not d["did_reset"][t]:
+            if rot:
+                np.testing.assert_array_equal(eng.get("cooldown")[0], d["st_cooldown"][t], err_msg="cooldown t=%d" % t)
+                np.testing.assert_allclose(eng.get("prev_proj")[0], d["st_prev_proj"][t], rtol=0, atol=2e-6, err_msg="prev_proj t=%d" % t)
             np.testing.assert_allclose(eng.get("x")[0], d["st_x"][t], rtol=0, atol=2e-6)
             np.testing.assert_array_equal(eng.get("status")[0].astype(bool), d["st_status"][t])
             np.testing.assert_array_equal(eng.get("prev_phase")[0], d["st_prev_phase"][t])
@@ -116,7 +123,7 @@ STATE_I = ["status", "prev_phase", "phase_reached", "cooldown", "goal_tracker", 
 
 
 def _compare_state(eng, orc, label):
-    for f in STATE_F + ["tube", "landmarks", "obstacles", "goal_min_time", "delta_spacing"]:
+    for f in STATE_F + ["tube", "landmarks", "obstacles", "goal_min_time", "delta_spacing", "prev_proj"]:
         np.testing.assert_allclose(eng.get(f), orc.get(f), rtol=0, atol=1e-9, err_msg=label + " " + f)
     for f in STATE_I:
         np.testing.assert_array_equal(eng.get(f), orc.get(f), err_msg=label + " " + f)
@@ -167,6 +174,23 @@ def test_july_random_rollout_vs_oracle_philox():
 def test_july_tube_transit_vs_oracle():
     cfg = gmpe.make_config(num_envs=64, num_agents=4, world_size=2.4, episode_length=40, seed=7)
     _rollout_vs_oracle(cfg, 45, seed=2, shrink_world=True)
+
+
+def test_rotinv_random_rollout_vs_oracle_philox():
+    cfg = gmpe.make_config(scenario_name=ROT, num_envs=96, num_agents=10, world_size=4.0, episode_length=12, seed=321)
+    assert cfg.node_feats == 7 and cfg.obs_dim == 13
+    assert _rollout_vs_oracle(cfg, 30, seed=5) >= 96 * 2
+
+
+def test_rotinv_tube_transit_vs_oracle():
+    """Agents pushed through the corridor: entrance-gate bonus + cooldown, progress reward, exit gate, goal reach."""
+    cfg = gmpe.make_config(scenario_name=ROT, num_envs=64, num_agents=4, world_size=2.4, episode_length=40, seed=9)
+    _rollout_vs_oracle(cfg, 45, seed=6, shrink_world=True)
+
+
+def test_rotinv_three_agents_and_64_agents():
+    _rollout_vs_oracle(gmpe.make_config(scenario_name=ROT, num_envs=5, num_agents=3, world_size=4.0, episode_length=9, seed=2), 20, seed=7)
+    _rollout_vs_oracle(gmpe.make_config(scenario_name=ROT, num_envs=3, num_agents=64, world_size=30.0, episode_length=4, seed=3), 9, seed=8)
 
 
 def test_july_small_config_c1():
@@ -349,7 +373,7 @@ def test_step_many_equals_host_loop():
 
 
 @pytest.mark.parametrize("G,B", [(2, 64), (6, 128), (3, 256)])
-@pytest.mark.parametrize("scen", ["nav_metered_one_goal_graph_rotate_tube_july", "navigation_graph"])
+@pytest.mark.parametrize("scen", ["nav_metered_one_goal_graph_rotate_tube_july", "navigation_graph", ROT])
 def test_packed_tiles_with_staggered_resets_vs_oracle(monkeypatch, G, B, scen):
     """Several envs per workgroup, and envs of one tile resetting at DIFFERENT steps (mixed tiles):
     the episode clocks are staggered through set_field so that resets are not simultaneous."""

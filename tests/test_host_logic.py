@@ -137,11 +137,15 @@ def test_spaces_are_duck_type_compatible():
 def test_lazy_infos_materialise_on_access():
     import torch
     from gmpe.vec_env import LazyInfos
-    raw = torch.arange(2 * 3 * 17, dtype=torch.float32).reshape(2, 3, 17)
+    K = len(gcfg.INFO_KEYS)
+    raw = torch.arange(2 * 3 * K, dtype=torch.float32).reshape(2, 3, K)
     li = LazyInfos(raw, 2, 3)
     assert li._host is None and len(li) == 2
     d = li[1][2]
-    assert list(d.keys()) == gcfg.INFO_KEYS and d["individual_reward"] == raw[1, 2, 0].item()
+    assert list(d.keys()) == gcfg.INFO_KEYS[:17] and d["individual_reward"] == raw[1, 2, 0].item()   # July / navigation_graph keys
+    r = LazyInfos(raw, 2, 3, include_phase=True)[1][2]                                               # rot_inv adds 'Phase_reached' (:835)
+    assert list(r.keys()) == gcfg.INFO_KEYS and r["Phase_reached"] == raw[1, 2, 17].item()
+    assert "Min_time_to_goal" not in LazyInfos(raw, 2, 3, include_min_time=False)[0][0]
     assert [len(x) for x in li] == [3, 3]
     # keys the runner prints (graph_mpe_runner.py:174-187)
     for k in ("Distance_mean", "Distance_variance", "Mean_by_variance", "Dist_to_goal", "individual_reward", "Num_agent_collisions"):
@@ -256,7 +260,7 @@ def test_oracle_under_sanitizers():
     """AddressSanitizer + UBSan on the CPU build of the oracle (the GPU pool has no ASan)."""
     out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "asan-run"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count("checksum") == 4 and "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr
+    assert out.stdout.count("checksum") == 5 and "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr
 
 
 def test_kernels_do_not_spill():
