@@ -1,0 +1,1098 @@
+// gmpe_kernel.h — the fused GraphMPE step / reset kernel template (see gmpe_step.hip for the overview).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "gmpe_device.h"
+
+namespace gmpe {
+
+enum { MODE_STEP = 0, MODE_RESET = 1 };
+// Scenario variant = compile-time parameter of the kernel: each variant's observation / reward / reset code is compiled
+// into its own instantiation (gmpe_sc.hip, one translation unit per variant), so adding a scenario never costs the
+// others registers. navigation_graph has a wall-less variant: the wall contact code is the largest register consumer.
+enum { SC_NAV = 0, SC_NAV_WALLS = 1, SC_JULY = 2, SC_ROT = 3, SC_COUNT = 4 };
+__host__ __device__ constexpr bool sc_kinematic(int sc) { return sc >= SC_JULY; }
+
+struct KParams {
+    gmpe_config c;
+    DevState s;
+    gmpe_outputs o;
+    const int32_t* act;       // [N,A] or nullptr
+    const float* onehot;      // [N,A,n_actions] or nullptr
+    const uint8_t* mask;      // reset mask or nullptr
+    int mode;
+    int A, L, O, E, D, F;     // F = node features per row (8, rot_inv: 7)
+    int G;                    // envs per workgroup (G*A <= 64)
+    int spec;                 // 1: multi-wave tiles specialise (wave 0 reward/info, waves 1.. graph stores)
+    int nt;                   // 1: nontemporal graph stores (outputs per launch exceed the 256 MiB Infinity Cache)
+    int ablate;               // debug: timing-only builds of the kernel skip parts (GMPE_ABLATE)
+    // magic multipliers for exact unsigned division by run-time constants (q < 2^22): floor(q/d) = umulhi(q, m)
+    uint32_t m_E, m_AE, m_EE, m_nq, m_2E, m_pe, m_AD, m_A, m_L, m_O, m_S, m_SS, m_C, m_AC, m_AEE, m_W, m_Sx, m_FW;
+    unsigned long long* stamps;   // diagnostic build only (-DGMPE_STAMPS): [grid][16] s_memtime per phase
+};
+__host__ __device__ inline uint32_t magic_of(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(0x100000000ull / d) + 1u; }
+__device__ __forceinline__ int fdiv(int q, int d, uint32_t m) { return d <= 1 ? q : (int)__umulhi((uint32_t)q, m); }
+
+// ---------------------------------------------------------------- LDS carve (dynamic, 16-B aligned)
+// A workgroup owns G consecutive environments (G*A <= 64: every agent of every env is one lane of
+// wave 0 for the sequential-semantics passes); all BLOCK threads share the O(E^2) distance pass and
+// the streaming stores. Arrays below hold G envs back to back.
+struct Lds {
+    double *ex, *ey;                  // [G][E]  entity positions (agents: post-integration)
+    double *s2, *s3;                  // [G][A]  theta/speed or vx/vy BEFORE this step's reward loop
+    double *n2, *n3;                  // [G][A]  ... AFTER it (reset_velocity on goal reach)
+    double *vox, *voy, *vnx, *vny;    // [G][A]  p_vel before / after
+    double *serr;                     // [G][A]  spacing error of this step (…_july.py:1168-1180)
+    double *cn, *sn;                  // [G][A]  cos / sin of the post-reward heading (rot_inv node features)
+    double *rew;                      // [G][A]
+    double *tube;                     // [G][12]
+    double *Dm;                       // [G][A][E] fp64 agent->entity distances (rows of cached_dist_mag)
+    int *s_old, *newf, *gt;           // [G][A]  status before, newly-reached flag, goal_tracker (final)
+    int *dtg_o, *dtg_n, *trq_o, *trq_n, *sv_o, *sv_n;   // [G][A] info counters old/new
+    int *flags;                       // [G][4]  0: reset this env, 1: heading draws this step, 2: env has masked nodes, 3: env active
+    int *moff;                        // [G][E]  adjacency mask per node (done agent / reached landmark)
+    int *ptab;                        // [A(A-1)/2] agent pairs (a<<8 | k), a < k, shared by the G envs of the tile
+    float *obs;                       // [G][A*D] staging
+    float *M;                         // [G][E*E] masked distance matrix, fp32
+};
+__host__ __device__ inline size_t lds_bytes(int G, int A, int E, int D) {
+    const size_t EE4 = ((size_t)E * E + 3) / 4 * 4, AD4 = ((size_t)A * D + 3) / 4 * 4;
+    size_t d = (size_t)G * (2 * E + 12 * A + 12 + (size_t)A * E);   // doubles
+    size_t f = (size_t)G * (EE4 + AD4);                             // floats
+    size_t i = (size_t)G * (9 * A + 4 + E) + (size_t)A * (A - 1) / 2 + 1;   // ints
+    return d * 8 + 16 + f * 4 + ((i * 4 + 15) / 16) * 16 + 32;
+}
+__device__ inline Lds carve(char* base, int G, int A, int E, int D) {
+    Lds l;
+    double* d = reinterpret_cast<double*>(base);
+    l.ex = d; d += G * E; l.ey = d; d += G * E;
+    l.s2 = d; d += G * A; l.s3 = d; d += G * A; l.n2 = d; d += G * A; l.n3 = d; d += G * A;
+    l.vox = d; d += G * A; l.voy = d; d += G * A; l.vnx = d; d += G * A; l.vny = d; d += G * A;
+    l.serr = d; d += G * A; l.cn = d; d += G * A; l.sn = d; d += G * A; l.rew = d; d += G * A; l.tube = d; d += G * 12;
+    l.Dm = d; d += (size_t)G * A * E;
+    if ((uintptr_t)d & 15) d += 1;
+    float* f = reinterpret_cast<float*>(d);
+    const size_t EE4 = ((size_t)E * E + 3) / 4 * 4, AD4 = ((size_t)A * D + 3) / 4 * 4;
+    l.M = f; f += (size_t)G * EE4;
+    l.obs = f; f += (size_t)G * AD4;
+    int* i = reinterpret_cast<int*>(f);
+    l.s_old = i; i += G * A; l.newf = i; i += G * A; l.gt = i; i += G * A;
+    l.dtg_o = i; i += G * A; l.dtg_n = i; i += G * A; l.trq_o = i; i += G * A; l.trq_n = i; i += G * A;
+    l.sv_o = i; i += G * A; l.sv_n = i; i += G * A; l.flags = i; i += G * 4; l.moff = i; i += G * E; l.ptab = i;
+    return l;
+}
+// view of env g inside the workgroup tile
+__device__ inline Lds env_view(const Lds& l, int g, int A, int E, int D) {
+    Lds v;
+    const size_t EE4 = ((size_t)E * E + 3) / 4 * 4, AD4 = ((size_t)A * D + 3) / 4 * 4;
+    v.ex = l.ex + g * E; v.ey = l.ey + g * E;
+    v.s2 = l.s2 + g * A; v.s3 = l.s3 + g * A; v.n2 = l.n2 + g * A; v.n3 = l.n3 + g * A;
+    v.vox = l.vox + g * A; v.voy = l.voy + g * A; v.vnx = l.vnx + g * A; v.vny = l.vny + g * A;
+    v.serr = l.serr + g * A; v.cn = l.cn + g * A; v.sn = l.sn + g * A; v.rew = l.rew + g * A; v.tube = l.tube + g * 12;
+    v.Dm = l.Dm + (size_t)g * A * E;
+    v.s_old = l.s_old + g * A; v.newf = l.newf + g * A; v.gt = l.gt + g * A;
+    v.dtg_o = l.dtg_o + g * A; v.dtg_n = l.dtg_n + g * A; v.trq_o = l.trq_o + g * A; v.trq_n = l.trq_n + g * A;
+    v.sv_o = l.sv_o + g * A; v.sv_n = l.sv_n + g * A; v.flags = l.flags + g * 4; v.moff = l.moff + g * E; v.ptab = l.ptab;
+    v.obs = l.obs + g * AD4; v.M = l.M + g * EE4;
+    return v;
+}
+
+// Streaming 16-byte store with the nontemporal hint (the observations are written once and read by another kernel).
+// Written as inline asm: with the builtin inside `if (p.nt) ... else plain store` the optimiser merges the two stores and
+// drops the hint. The asm statement carries its own wait state (cdna_hip_programming.md §5.7 item 2); a store has no
+// result to wait for, and the kernel issues no load after these stores.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store4(float4* dst, const float4& v) {
+    v4f_t x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dst), "v"(x) : "memory");
+}
+
+template <int SC>
+__device__ __forceinline__ void vel_of(double a2, double a3, double& vx, double& vy) {
+    if (sc_kinematic(SC)) { double sn, cs; sincos(a2, &sn, &cs); vx = a3 * cs; vy = a3 * sn; }      // core.py:281-286
+    else { vx = a2; vy = a3; }                                       // core.py:191-193
+}
+
+__device__ __forceinline__ bool wall_band_hit(const KParams& p, double px, double py, double size) {
+    for (int w = 0; w < p.c.num_walls; ++w) {
+        const gmpe_wall& wl = p.c.walls[w];
+        const double band = 1.5 * size;
+        const double perp = wl.orient == 0 ? py : px, prll = wl.orient == 0 ? px : py;
+        if (wl.axis_pos - band <= perp && perp <= wl.axis_pos + band && wl.end0 - band <= prll && prll <= wl.end1 + band)
+            return true;
+    }
+    return false;
+}
+// Scenario.is_obstacle_collision (…_july.py:864-890) at an arbitrary point (reset placement)
+__device__ __forceinline__ bool obstacle_collision(const KParams& p, const Lds& l, double px, double py, double size) {
+    const int o0 = p.A + p.L;
+    for (int o = 0; o < p.O; ++o)
+        if (norm2(l.ex[o0 + o] - px, l.ey[o0 + o] - py) < 2.0 * (p.c.entity_size + size)) return true;
+    return wall_band_hit(p, px, py, size);
+}
+// same test for agent i at its current position, distances taken from the shared fp64 rows
+__device__ __forceinline__ bool obstacle_collision_ego(const KParams& p, const Lds& l, int i) {
+    const double* row = l.Dm + (size_t)i * p.E + p.A + p.L;
+    for (int o = 0; o < p.O; ++o)
+        if (row[o] < 2.0 * (p.c.entity_size + p.c.entity_size)) return true;
+    return wall_band_hit(p, l.ex[i], l.ey[i], p.c.entity_size);
+}
+
+// _set_action (environment.py:336-475)
+template <int SC>
+__device__ __forceinline__ void decode_action(const gmpe_config& c, int idx, double& u0, double& u1) {
+    if (!sc_kinematic(SC)) {
+        if (c.n_actions == 5) {
+            u0 = (idx == 1 ? 1.0 : 0.0) - (idx == 2 ? 1.0 : 0.0);
+            u1 = (idx == 3 ? 1.0 : 0.0) - (idx == 4 ? 1.0 : 0.0);
+        } else {                                                     // action_map 382-392
+            const double d = 0.71;
+            u0 = (idx == 1 ? -1.0 : idx == 5 ? 1.0 : (idx == 2 || idx == 8) ? -d : (idx == 4 || idx == 6) ? d : 0.0);
+            u1 = (idx == 3 ? -1.0 : idx == 7 ? 1.0 : (idx == 2 || idx == 4) ? -d : (idx == 6 || idx == 8) ? d : 0.0);
+        }
+    } else {
+        const int wi = idx / 5, ai = idx - wi * 5;
+        u0 = wi == 0 ? c.ang_rate_opt[0] : wi == 1 ? c.ang_rate_opt[1] : wi == 2 ? c.ang_rate_opt[2] : wi == 3 ? c.ang_rate_opt[3] : c.ang_rate_opt[4];
+        u1 = ai == 0 ? c.accel_opt[0] : ai == 1 ? c.accel_opt[1] : ai == 2 ? c.accel_opt[2] : ai == 3 ? c.accel_opt[3] : c.accel_opt[4];
+    }
+    u0 *= c.sensitivity; u1 *= c.sensitivity;
+}
+
+// Scenario.observation (…_july.py:1337-1463) for ego i into the LDS staging row; `phase` = value of
+// the first get_agent_phase call of the step. Uses the PRE-reward own velocity (vox/voy).
+template <int AP, int SC>
+__device__ __forceinline__ void write_obs(const KParams& p, const Lds& l, int i, double vx, double vy, int phase) {
+    float* o = l.obs + (size_t)i * p.D;
+    const double px = l.ex[i], py = l.ey[i];
+    const double gx = l.ex[p.A + i] - px, gy = l.ey[p.A + i] - py;
+    o[0] = (float)px; o[1] = (float)py; o[2] = (float)vx; o[3] = (float)vy;
+    o[4] = (float)gx; o[5] = (float)gy; o[6] = 0.0f; o[7] = (float)gx; o[8] = (float)gy;
+    // stable two-smallest of the other agents (1398-1417): strict '<' keeps the first of equal distances
+    const double INF = __builtin_huge_val();
+    int b1 = -1, b2 = -1; double d1 = INF, d2 = INF;
+    const double* row = l.Dm + (size_t)i * p.E;
+    if (AP) {
+        double rv[AP ? AP : 1];
+#pragma unroll
+        for (int k = 0; k < AP; ++k) rv[k] = row[k < p.A ? k : 0];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < AP; ++k) {
+            const double d = (k < p.A && k != i) ? rv[k] : INF;
+            const bool lt1 = d < d1, lt2 = d < d2;
+            d2 = lt1 ? d1 : (lt2 ? d : d2); b2 = lt1 ? b1 : (lt2 ? k : b2);
+            d1 = lt1 ? d : d1; b1 = lt1 ? k : b1;
+        }
+    } else {
+        for (int k = 0; k < p.A; ++k) {
+            const double d = k != i ? row[k] : INF;
+            const bool lt1 = d < d1, lt2 = d < d2;
+            d2 = lt1 ? d1 : (lt2 ? d : d2); b2 = lt1 ? b1 : (lt2 ? k : b2);
+            d1 = lt1 ? d : d1; b1 = lt1 ? k : b1;
+        }
+    }
+    o[9] = b1 >= 0 ? (float)(l.ex[b1] - px) : 0.f; o[10] = b1 >= 0 ? (float)(l.ey[b1] - py) : 0.f;
+    o[11] = b2 >= 0 ? (float)(l.ex[b2] - px) : 0.f; o[12] = b2 >= 0 ? (float)(l.ey[b2] - py) : 0.f;
+    if (SC == SC_JULY) {
+        o[13] = (float)(l.tube[T_ENTX] - px); o[14] = (float)(l.tube[T_ENTY] - py);
+        o[15] = (float)(l.tube[T_EXX] - px); o[16] = (float)(l.tube[T_EXY] - py);
+        o[17] = (float)l.tube[T_WIDTH]; o[18] = (float)phase;
+    }
+}
+
+// Scenario.observation of rot_inv (…rot_inv.py:1453-1548): 13 float32 = [cos th, sin th, speed, goal (rotated), two nearest
+// neighbours (rel. vector cast to float32, then rotated in float64), s/L, y/half_w (clipped), exit-gate distance / L, phase].
+// Uses the PRE-reward heading (the reward of this agent runs after its observation).
+template <int AP>
+__device__ __forceinline__ void write_obs_rot(const KParams& p, const Lds& l, int i, int phase) {
+    float* o = l.obs + (size_t)i * p.D;
+    const double px = l.ex[i], py = l.ey[i], th = l.s2[i];
+    double sn, cs; sincos(th, &sn, &cs);
+    const double INF = __builtin_huge_val();
+    int b1 = -1, b2 = -1; double d1 = INF, d2 = INF;
+    const double* row = l.Dm + (size_t)i * p.E;
+    for (int k = 0; k < p.A; ++k) {
+        const double d = k != i ? row[k] : INF;
+        const bool lt1 = d < d1, lt2 = d < d2;
+        d2 = lt1 ? d1 : (lt2 ? d : d2); b2 = lt1 ? b1 : (lt2 ? k : b2);
+        d1 = lt1 ? d : d1; b1 = lt1 ? k : b1;
+    }
+    double gx, gy; rot2(cs, sn, l.ex[p.A + i] - px, l.ey[p.A + i] - py, gx, gy);
+    double n1x = 0, n1y = 0, n2x = 0, n2y = 0;
+    if (b1 >= 0) rot2(cs, sn, (double)(float)(l.ex[b1] - px), (double)(float)(l.ey[b1] - py), n1x, n1y);
+    if (b2 >= 0) rot2(cs, sn, (double)(float)(l.ex[b2] - px), (double)(float)(l.ey[b2] - py), n2x, n2y);
+    const double L = l.tube[T_L], hw = l.tube[T_HALFW];
+    double s, yy; tube_sy(l.tube, px, py, s, yy);
+    o[0] = (float)cs; o[1] = (float)sn; o[2] = (float)l.s3[i];
+    o[3] = (float)gx; o[4] = (float)gy; o[5] = (float)n1x; o[6] = (float)n1y; o[7] = (float)n2x; o[8] = (float)n2y;
+    o[9] = (float)clipd(s / L, -2.0, 2.0); o[10] = (float)clipd(yy / (hw + 1e-9), -2.0, 2.0);
+    o[11] = (float)(exit_gate_distance(s, yy, L, hw) / (L + 1e-9)); o[12] = (float)phase;
+}
+
+// Serial reset of one env by ONE lane (reset_world: …_july.py:339-420, 440-515, 518-613,
+// custom_scenarios/utils.py:165-193; navigation_graph: DESIGN.md). Writes positions / headings to
+// LDS (ex, ey, n2, n3, tube) and landmark / obstacle / tube records to HBM. Bounded rejection loop.
+template <int SC>
+__device__ __forceinline__ void reset_world_serial(const KParams& p, const Lds& l, int n, int64_t& ctr, int& err) {
+    const gmpe_config& c = p.c;
+    const double ws = c.world_size, size = c.entity_size;
+    const int A = p.A, L = p.L, O = p.O;
+    if (sc_kinematic(SC)) {
+        (void)draw_at(c, p.s, n, ctr++, err);                              // wall_length draw, unused (:368)
+        const double a = 3 * size * 2.5, b = ws * 0.15;
+        const double width = a > b ? a : b;
+        const double angle = -M_PI / 2 + (M_PI / 2 - (-M_PI / 2)) * draw_at(c, p.s, n, ctr++, err);
+        const double tl = ws * 0.8;
+        const double ca = cos(angle), sa = sin(angle);
+        const double be = tl / 4, bx = -tl / 4;
+        const double entx = ca * 0 + sa * be, enty = -sa * 0 + ca * be;
+        const double exx = ca * 0 + sa * bx, exy = -sa * 0 + ca * bx;
+        const double dx = exx - entx, dy = exy - enty;
+        const double Lt = sqrt(dx * dx + dy * dy) + 1e-9;
+        const double ex = dx / Lt, ey = dy / Lt;
+        double* t = l.tube;
+        t[T_ANGLE] = angle; t[T_ENTX] = entx; t[T_ENTY] = enty; t[T_EXX] = exx; t[T_EXY] = exy;
+        t[T_EX] = ex; t[T_EY] = ey; t[T_NX] = (double)(float)(-ey); t[T_NY] = (double)(float)ex;
+        t[T_L] = Lt; t[T_HALFW] = width * 0.5; t[T_WIDTH] = width;
+        for (int q = 0; q < GMPE_TUBE_STRIDE; ++q) p.s.tube[(size_t)n * GMPE_TUBE_STRIDE + q] = t[q];
+        int k = 0, tries = 0;
+        while (k < A) {
+            const double u0 = draw_at(c, p.s, n, ctr++, err), u1 = draw_at(c, p.s, n, ctr++, err);
+            constexpr bool rot = SC == SC_ROT;              // rot_inv.py:463, 469
+            const double jf = rot ? 0.3 : 0.2;
+            const double jx = jf * (-ws + (ws - (-ws)) * u0), jy = jf * (-ws + (ws - (-ws)) * u1);
+            const double dfe = rot ? (ws + k) / 3 : (ws + k) / 5;
+            const double px = entx + dfe * sa + jx, py = enty + dfe * ca + jy;
+            bool bad = obstacle_collision(p, l, px, py, size);
+            for (int q = 0; q < k && !bad; ++q) bad = norm2(l.ex[q] - px, l.ey[q] - py) < c.sep_dist;
+            if (bad && ++tries < GMPE_MAX_TRIES) continue;
+            if (bad) err |= 2;
+            l.ex[k] = px; l.ey[k] = py;
+            l.n2[k] = 0.0 + (2 * M_PI - 0.0) * draw_at(c, p.s, n, ctr++, err);
+            l.n3[k] = c.v_min;
+            ++k; tries = 0;
+        }
+        const double rel = -ws / 3;
+        const double rx = ca * 0.0 + sa * rel, ry = -sa * 0.0 + ca * rel;
+        for (int q = 0; q < L; ++q) { l.ex[A + q] = exx + rx; l.ey[A + q] = exy + ry; }
+    } else {
+        const double lo = -ws / 2, hi = ws / 2;
+        for (int o = 0, tries = 0; o < O;) {
+            const double px = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr, err));
+            const double py = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr + 1, err));
+            ctr += 2;
+            bool bad = false;
+            for (int q = 0; q < o && !bad; ++q) bad = norm2(l.ex[A + L + q] - px, l.ey[A + L + q] - py) < 2.0 * (size + size);
+            if (bad && ++tries < GMPE_MAX_TRIES) continue;
+            if (bad) err |= 2;
+            l.ex[A + L + o] = px; l.ey[A + L + o] = py; ++o; tries = 0;
+        }
+        for (int k = 0, tries = 0; k < A;) {
+            const double px = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr, err));
+            const double py = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr + 1, err));
+            ctr += 2;
+            bool bad = obstacle_collision(p, l, px, py, size);
+            for (int q = 0; q < k && !bad; ++q) bad = norm2(l.ex[q] - px, l.ey[q] - py) < c.sep_dist;
+            if (bad && ++tries < GMPE_MAX_TRIES) continue;
+            if (bad) err |= 2;
+            l.ex[k] = px; l.ey[k] = py; l.n2[k] = 0.0; l.n3[k] = 0.0; ++k; tries = 0;
+        }
+        for (int q = 0, tries = 0; q < L;) {
+            const double px = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr, err));
+            const double py = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr + 1, err));
+            ctr += 2;
+            bool bad = obstacle_collision(p, l, px, py, size);
+            for (int r = 0; r < q && !bad; ++r) bad = norm2(l.ex[A + r] - px, l.ey[A + r] - py) < c.sep_dist;
+            if (bad && ++tries < GMPE_MAX_TRIES) continue;
+            if (bad) err |= 2;
+            l.ex[A + q] = px; l.ey[A + q] = py; ++q; tries = 0;
+        }
+        for (int o = 0; o < O; ++o) {
+            p.s.obstacles[((size_t)n * O + o) * 2] = l.ex[A + L + o];
+            p.s.obstacles[((size_t)n * O + o) * 2 + 1] = l.ey[A + L + o];
+        }
+    }
+    for (int q = 0; q < L; ++q) {
+        p.s.landmarks[((size_t)n * L + q) * 2] = l.ex[A + q];
+        p.s.landmarks[((size_t)n * L + q) * 2 + 1] = l.ey[A + q];
+    }
+}
+
+
+// Post-move distance pass for every env of the tile (World.calculate_distances, core.py:600-624:
+// delta taken as pos[min]-pos[max], so the matrix is exactly symmetric). Writes the fp64 agent rows
+// Dm[g][r][c] AND the unmasked fp32 matrix M (agent rows + their mirrored columns); the static
+// (landmark/obstacle) x (landmark/obstacle) block is filled by static_block().
+template <int BLOCK>
+__device__ __forceinline__ void distance_pass(const KParams& p, const Lds& l, int G, int tid, bool only_reset) {
+    const int A = p.A, E = p.E, AE = A * E, EE4 = (E * E + 3) / 4 * 4;
+    const int NP = A * (A - 1) / 2, S = E - A, AS = A * S, W = NP + AS;   // per env: agent pairs + agent x static entities
+    const int total = G * W;
+    for (int q0 = tid; q0 < total; q0 += 2 * BLOCK) {                   // two independent entries per trip
+        double ds[2]; int gs[2], rs[2], cs[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = q0 + u * BLOCK;
+            const bool live = q < total;
+            const int qq = live ? q : tid;
+            const int g = fdiv(qq, W, p.m_W), w = qq - g * W;
+            const bool ap_ = w < NP;
+            const int pk = l.ptab[ap_ ? w : 0];
+            const int t = ap_ ? 0 : w - NP;
+            const int ro = fdiv(t, S, p.m_Sx);
+            const int r = ap_ ? (pk >> 8) : ro, cc = ap_ ? (pk & 255) : A + (t - ro * S);   // r < cc always
+            const double dx = l.ex[g * E + r] - l.ex[g * E + cc], dy = l.ey[g * E + r] - l.ey[g * E + cc];
+            ds[u] = sqrt(dx * dx + dy * dy);
+            gs[u] = (live && !(only_reset && !l.flags[g * 4 + 0])) ? g : -1; rs[u] = r; cs[u] = cc;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (gs[u] < 0) continue;
+            const int r = rs[u], cc = cs[u];
+            double* Dg = l.Dm + (size_t)gs[u] * AE;
+            float* Mg = l.M + (size_t)gs[u] * EE4;
+            const float df = (float)ds[u];
+            Dg[r * E + cc] = ds[u]; Mg[r * E + cc] = df; Mg[cc * E + r] = df;
+            if (cc < A) Dg[cc * E + r] = ds[u];
+        }
+    }
+    for (int q = tid; q < G * A; q += BLOCK) {                           // diagonal
+        const int g = fdiv(q, A, p.m_A), r = q - g * A;
+        if (only_reset && !l.flags[g * 4 + 0]) continue;
+        l.Dm[(size_t)g * AE + r * E + r] = 0.0; l.M[(size_t)g * EE4 + r * E + r] = 0.0f;
+    }
+}
+template <int BLOCK>
+__device__ __forceinline__ void static_block(const KParams& p, const Lds& l, int G, int tid, bool only_reset) {
+    const int A = p.A, E = p.E, S = p.L + p.O, SS = S * S, EE4 = (E * E + 3) / 4 * 4;
+    for (int q = tid; q < G * SS; q += BLOCK) {
+        const int g = fdiv(q, SS, p.m_SS), rc = q - g * SS, r3 = fdiv(rc, S, p.m_S), c3 = rc - r3 * S;
+        if (only_reset && !l.flags[g * 4 + 0]) continue;
+        const int r = A + r3, cc = A + c3;
+        const int a = r < cc ? r : cc, b = r < cc ? cc : r;
+        const double dx = l.ex[g * E + a] - l.ex[g * E + b], dy = l.ey[g * E + a] - l.ey[g * E + b];
+        l.M[(size_t)g * EE4 + r * E + cc] = r != cc ? (float)sqrt(dx * dx + dy * dy) : 0.0f;
+    }
+}
+
+#define SWEEP(var, n) _Pragma("unroll") for (int var = 0; var < (AP ? AP : (n)); ++var)
+// Graph outputs of a tile: optional adjacency mask pass (block-wide, with its barrier), then the adj and node_obs
+// stores executed by threads t0, t0+nthr, ... (all BLOCK threads, or only the streaming waves of a specialised tile).
+template <int BLOCK, int AP, int SC>
+__device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, const int Gv, const int n0, const int tid,
+                                                const int t0, const int nthr, const bool do_mask, const int any_mask) {
+    const int A = p.A, L = p.L, E = p.E, EE = E * E, EE4 = (EE + 3) / 4 * 4;
+    const int abl = p.ablate;
+    // ---- 6. adjacency mask (…_july.py:1627-1648): rows/cols of done agents and reached landmarks -> 0.
+    // Only tiles that contain such an entity pay for this pass.
+    if (do_mask && any_mask && !(abl & 4)) {
+        for (int q = tid; q < Gv * EE; q += BLOCK) {
+            const int gg = fdiv(q, EE, p.m_EE), rc = q - gg * EE;
+            if (!l.flags[gg * 4 + 2]) continue;
+            const int r = fdiv(rc, E, p.m_E), cc = rc - r * E;
+            if (l.moff[gg * E + r] | l.moff[gg * E + cc]) l.M[(size_t)gg * EE4 + rc] = 0.0f;
+        }
+    }
+    if (do_mask) __syncthreads();
+    
+
+    // ---- 7. stream the observations out (16-byte stores wherever the row length allows)
+    if (p.o.adj && !(abl & 1)) {
+        const bool vec = (EE & 3) == 0;
+        if (p.o.adj_compact) {
+            float* dst = p.o.adj + (size_t)n0 * EE;
+            if (vec) {
+                const int nq = EE / 4;
+                for (int q = t0; q < Gv * nq; q += nthr) {
+                    const int gg = fdiv(q, nq, p.m_nq), m = q - gg * nq;
+                    if (l.flags[gg * 4 + 3]) reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(l.M + (size_t)gg * EE4)[m];
+                }
+            } else for (int q = t0; q < Gv * EE; q += nthr) { const int gg = fdiv(q, EE, p.m_EE); if (l.flags[gg * 4 + 3]) dst[q] = l.M[(size_t)gg * EE4 + (q - gg * EE)]; }
+        } else {
+            float* dst = p.o.adj + (size_t)n0 * A * EE;
+            if (vec) {
+                const int nq = EE / 4;
+                // each lane keeps one float4 of the env's matrix and stores it to the A ego copies
+                for (int q = t0; q < Gv * nq; q += nthr) {
+                    const int gg = fdiv(q, nq, p.m_nq), m = q - gg * nq;
+                    if (!l.flags[gg * 4 + 3]) continue;
+                    const float4 val = reinterpret_cast<const float4*>(l.M + (size_t)gg * EE4)[m];
+                    float4* d4 = reinterpret_cast<float4*>(dst) + (size_t)gg * A * nq + m;
+                    SWEEP(a, A) { if (!AP || a < A) { if (p.nt) nt_store4(&d4[(size_t)a * nq], val); else d4[(size_t)a * nq] = val; } }
+                }
+            } else {
+                const int AEE = A * EE;
+                for (int q = t0; q < Gv * AEE; q += nthr) {
+                    const int gg = q / AEE, rem = q - gg * AEE, rc = rem % EE;    // rare path (E*E % 4 != 0): plain division
+                    if (l.flags[gg * 4 + 3]) dst[q] = l.M[(size_t)gg * EE4 + rc];
+                }
+            }
+        }
+    }
+    
+    if (SC == SC_ROT && p.o.node_obs && !(abl & 2)) {
+        // rot_inv node row (…rot_inv.py:1690-1766): 7 float32 = [rel_vel, rel_pos, rel_goal (all rotated by the ego heading), type].
+        // Positions / velocities are rounded to float32 FIRST, differenced in float32, rotated in float64, rounded again.
+        // A lane owns one (env, entity) and walks the egos; rows are 28 B, so the stores are scalar.
+        float* base = p.o.node_obs + (size_t)n0 * A * E * 7;
+        for (int sidx = t0; sidx < Gv * E; sidx += nthr) {
+            const int gg = fdiv(sidx, E, p.m_E), k = sidx - gg * E;
+            if (!l.flags[gg * 4 + 3]) continue;
+            const int ab = gg * A, eb = gg * E;
+            const bool kag = k < A;
+            const int kk = kag ? k : 0;
+            const float kx = (float)l.ex[eb + k], ky = (float)l.ey[eb + k];
+            const float kvox = kag ? (float)l.vox[ab + kk] : 0.0f, kvoy = kag ? (float)l.voy[ab + kk] : 0.0f;
+            const float kvnx = kag ? (float)l.vnx[ab + kk] : 0.0f, kvny = kag ? (float)l.vny[ab + kk] : 0.0f;
+            const bool knew = kag && l.newf[ab + kk] != 0;
+            const float gxk = kag ? (float)l.ex[eb + A + kk] : 0.0f, gyk = kag ? (float)l.ey[eb + A + kk] : 0.0f;
+            const float typ = kag ? 0.0f : (k < A + L ? 1.0f : 2.0f);
+            for (int ei = 0; ei < A; ++ei) {
+                const float apx = (float)l.ex[eb + ei], apy = (float)l.ey[eb + ei];
+                const bool en = l.newf[ab + ei] != 0;
+                const float avx = (float)(en ? l.vnx[ab + ei] : l.vox[ab + ei]), avy = (float)(en ? l.vny[ab + ei] : l.voy[ab + ei]);
+                const double cs = l.cn[ab + ei], sn = l.sn[ab + ei];          // ego heading AFTER its own reward
+                const bool post = knew && k <= ei;
+                const float rvx = (post ? kvnx : kvox) - avx, rvy = (post ? kvny : kvoy) - avy;
+                const float rpx = kx - apx, rpy = ky - apy;
+                double o0, o1, o2, o3, o4, o5;
+                rot2(cs, sn, (double)rvx, (double)rvy, o0, o1);
+                rot2(cs, sn, (double)rpx, (double)rpy, o2, o3);
+                if (kag) rot2(cs, sn, (double)(gxk - apx), (double)(gyk - apy), o4, o5); else { o4 = o2; o5 = o3; }
+                float* dst = base + ((size_t)(gg * A + ei) * E + k) * 7;
+                dst[0] = (float)o0; dst[1] = (float)o1; dst[2] = (float)o2; dst[3] = (float)o3;
+                dst[4] = (float)o4; dst[5] = (float)o5; dst[6] = typ;
+            }
+        }
+    }
+    if (SC != SC_ROT && p.o.node_obs && !(abl & 2)) {
+        // node row (ego, entity k) = 2 float4: [rel_vel, rel_pos] and [rel_goal, occupied, type].
+        // A lane owns one (env, entity, half) slot, keeps that entity's data in registers and walks the egos.
+        float4* base = reinterpret_cast<float4*>(p.o.node_obs + (size_t)n0 * A * E * GMPE_NODE_FEATS);
+        const int E2 = 2 * E;
+        for (int sidx = t0; sidx < Gv * E2; sidx += nthr) {
+            const int gg = fdiv(sidx, E2, p.m_2E), rem = sidx - gg * E2;
+            if (!l.flags[gg * 4 + 3]) continue;
+            const int k = rem >> 1, half = rem & 1;
+            const int ab = gg * A, eb = gg * E;
+            const double kx = l.ex[eb + k], ky = l.ey[eb + k];
+            const bool kag = k < A;
+            const int kk = kag ? k : 0;
+            const double kvox = kag ? l.vox[ab + kk] : 0.0, kvoy = kag ? l.voy[ab + kk] : 0.0;
+            const double kvnx = kag ? l.vnx[ab + kk] : 0.0, kvny = kag ? l.vny[ab + kk] : 0.0;
+            const bool knew = kag && l.newf[ab + kk] != 0;
+            const double gx = kag ? l.ex[eb + A + kk] : kx, gy = kag ? l.ey[eb + A + kk] : ky;
+            const float occ = kag ? 0.0f : 1.0f, typ = kag ? 0.0f : (k < A + L ? 1.0f : 2.0f);
+            float4* dst = base + (size_t)gg * A * E2 + rem;
+            SWEEP(ei, A) {
+                const bool ok = !AP || ei < A;
+                const int ec = ok ? ei : 0;
+                const double px = l.ex[eb + ec], py = l.ey[eb + ec];
+                const bool en = l.newf[ab + ec] != 0;
+                const double evox = l.vox[ab + ec], evoy = l.voy[ab + ec], evnx = l.vnx[ab + ec], evny = l.vny[ab + ec];
+                float4 val;
+                if (half == 0) {
+                    const double evx = en ? evnx : evox, evy = en ? evny : evoy;
+                    const bool post = knew && k <= ec;
+                    val = make_float4((float)((post ? kvnx : kvox) - evx), (float)((post ? kvny : kvoy) - evy), (float)(kx - px), (float)(ky - py));
+                } else {
+                    val = make_float4((float)(gx - px), (float)(gy - py), occ, typ);
+                }
+                if (ok) { if (p.nt) nt_store4(&dst[(size_t)ec * E2], val); else dst[(size_t)ec * E2] = val; }
+            }
+        }
+    }
+}
+
+#ifndef GMPE_MIN_WAVES
+#define GMPE_MIN_WAVES 1
+#endif
+#ifndef GMPE_MIN_WAVES_NOWALLS
+#define GMPE_MIN_WAVES_NOWALLS 1
+#endif
+#ifdef GMPE_STAMPS
+#define STAMP(k) do { if (tid == 0 && p.stamps) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+// ---------------------------------------------------------------- the fused kernel
+// AP > 0: compile-time bound (A, L <= AP) for the per-agent sweeps, so they unroll fully and every LDS read of a
+// sweep is issued before the first use (the sweeps are latency-bound: one wave per SIMD, ~100-cycle LDS reads).
+// Out-of-range iterations read a clamped index and are masked in the arithmetic. AP == 0: run-time bounds.
+// SC: scenario variant (above). Only SC_NAV_WALLS compiles the wall-contact code (asin / cos / softplus inside the agent lane's dynamics) out: it is
+// the single largest consumer of registers (187 -> 135 VGPRs), i.e. 2 -> 3 waves per SIMD for wall-less worlds.
+template <int BLOCK, int AP, int SC>
+__global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOWALLS)) void k_env(const KParams p) {
+    constexpr bool WALLS = SC == SC_NAV_WALLS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int A = p.A, L = p.L, O = p.O, E = p.E, D = p.D, G = p.G, N = p.c.num_envs;
+    const gmpe_config& c = p.c;
+    const Lds l = carve(smem, G, A, E, D);
+    const int n0 = blockIdx.x * G;
+    const int Gv = min(G, N - n0);                                      // envs actually present in this tile
+    constexpr bool july = SC == SC_JULY, rotinv = SC == SC_ROT;
+    const bool step = p.mode == MODE_STEP;
+    constexpr bool kin = sc_kinematic(SC);
+    const int EE = E * E, EE4 = (EE + 3) / 4 * 4, AD4 = (A * D + 3) / 4 * 4;
+    const double INF = __builtin_huge_val();
+
+    // agent lane mapping: lane tid of wave 0 = (env g, agent i)
+    const int g = fdiv(tid, A, p.m_A), i = tid - g * A;
+    const int n = n0 + g;
+    bool ag = tid < Gv * A;
+    if (ag && !step && p.mask && !p.mask[n]) ag = false;               // explicit reset: masked-out env
+    const size_t na = (size_t)n * A + i;
+    const Lds v = env_view(l, ag ? g : 0, A, E, D);
+    const unsigned long long emask = ag ? ((A >= 64 ? ~0ull : ((1ull << A) - 1ull)) << (g * A)) : 0ull;
+
+    // ---- per-agent registers
+    int prev_phase = 0, phase_reached = 0, cooldown = 0;
+    double p_dist = 0, tim = 0;
+    int trq = -1, dtg = -1, dleft = -1, greached = -1, nac = 0, noc = 0, sv = 0, sic = 0, conf = 0;
+    double gmt = 0, dsp0 = 0, pproj = 0;
+    int cur_step = 0, act_idx = 0;
+    int err = 0;
+    int64_t ctr0 = 0;
+
+    STAMP(0);
+    // ---- 0. load state. Every global read of the step is ISSUED here before any of them is consumed
+    // (first iteration of each staging loop hoisted into registers), so the tile pays one HBM round trip.
+    const bool t_ok = tid < Gv * GMPE_TUBE_STRIDE, l_ok = tid < Gv * L, o_ok = tid < Gv * O;
+    double tube0 = 0, lmx0 = 0, lmy0 = 0, obx0 = 0, oby0 = 0;
+    if (t_ok) tube0 = p.s.tube[(size_t)n0 * GMPE_TUBE_STRIDE + tid];
+    if (l_ok) { lmx0 = p.s.landmarks[((size_t)n0 * L + tid) * 2]; lmy0 = p.s.landmarks[((size_t)n0 * L + tid) * 2 + 1]; }
+    if (o_ok) { obx0 = p.s.obstacles[((size_t)n0 * O + tid) * 2]; oby0 = p.s.obstacles[((size_t)n0 * O + tid) * 2 + 1]; }
+    double x0 = 0, y0 = 0, a20 = 0, a30 = 0; int st0 = 0, gt0 = -1;
+    if (ag) {
+        prev_phase = p.s.prev_phase[na];
+        cur_step = p.s.current_step[n];
+        ctr0 = p.s.rng_ctr[n];
+        if (step) {
+            x0 = p.s.x[na]; y0 = p.s.y[na]; a20 = p.s.s2[na]; a30 = p.s.s3[na];
+            st0 = p.s.status[na]; gt0 = p.s.goal_tracker[na];
+            phase_reached = p.s.phase_reached[na]; cooldown = p.s.cooldown[na];
+            p_dist = p.s.p_dist[na]; tim = p.s.time[na];
+            trq = p.s.times_required[na]; dtg = p.s.dists_to_goal[na]; dleft = p.s.dist_left[na];
+            greached = p.s.goal_reached[na]; nac = p.s.n_agent_coll[na]; noc = p.s.n_obst_coll[na];
+            sv = p.s.spacing_viol[na]; sic = p.s.steps_in_corr[na]; conf = p.s.conformance[na];
+            gmt = p.s.goal_min_time[na];
+            if (rotinv) pproj = p.s.prev_proj[na];
+            dsp0 = p.s.delta_spacing[n];
+            if (p.act) act_idx = p.act[na];
+            else {                                                      // np.argmax: first maximum
+                const float* oh = p.onehot + na * c.n_actions;
+                float best = oh[0];
+                for (int q = 1; q < c.n_actions; ++q) { const float x = oh[q]; if (x > best) { best = x; act_idx = q; } }
+            }
+        }
+    }
+    for (int q = tid; q < G * E; q += BLOCK) l.moff[q] = 0;
+    for (int q = tid; q < A * A; q += BLOCK) {                          // agent-pair table (a < k), row-major triangular order
+        const int a = fdiv(q, A, p.m_A), k = q - a * A;
+        if (k > a) l.ptab[a * A - a * (a + 1) / 2 + (k - a - 1)] = (a << 8) | k;
+    }
+    if (tid < G) {
+        const int nn = n0 + tid;
+        const bool active = nn < N && (step || !p.mask || p.mask[nn]);
+        l.flags[tid * 4 + 0] = (!step && active); l.flags[tid * 4 + 1] = 0; l.flags[tid * 4 + 2] = 0; l.flags[tid * 4 + 3] = active;
+    }
+    if (t_ok) l.tube[tid] = tube0;
+    for (int q = tid + BLOCK; q < Gv * GMPE_TUBE_STRIDE; q += BLOCK) l.tube[q] = p.s.tube[(size_t)n0 * GMPE_TUBE_STRIDE + q];
+    if (l_ok) { const int gg = fdiv(tid, L, p.m_L), k = tid - gg * L; l.ex[gg * E + A + k] = lmx0; l.ey[gg * E + A + k] = lmy0; }
+    for (int q = tid + BLOCK; q < Gv * L; q += BLOCK) {
+        const int gg = fdiv(q, L, p.m_L), k = q - gg * L;
+        l.ex[gg * E + A + k] = p.s.landmarks[((size_t)n0 * L + q) * 2]; l.ey[gg * E + A + k] = p.s.landmarks[((size_t)n0 * L + q) * 2 + 1];
+    }
+    if (o_ok) { const int gg = fdiv(tid, O, p.m_O), k = tid - gg * O; l.ex[gg * E + A + L + k] = obx0; l.ey[gg * E + A + L + k] = oby0; }
+    for (int q = tid + BLOCK; q < Gv * O; q += BLOCK) {
+        const int gg = fdiv(q, O, p.m_O), k = q - gg * O;
+        l.ex[gg * E + A + L + k] = p.s.obstacles[((size_t)n0 * O + q) * 2]; l.ey[gg * E + A + L + k] = p.s.obstacles[((size_t)n0 * O + q) * 2 + 1];
+    }
+    if (ag && step) {
+        v.ex[i] = x0; v.ey[i] = y0; v.s2[i] = a20; v.s3[i] = a30; v.s_old[i] = st0; v.gt[i] = gt0;
+        act_idx = act_idx < 0 ? 0 : (act_idx >= c.n_actions ? c.n_actions - 1 : act_idx);
+    }
+    __syncthreads();
+    STAMP(1);
+
+    int ph1 = 0, cp = 0, prevA = 0;
+    bool goal_branch = true, done = false, all_done = false;
+    double dgoal = 0, rew = 0;
+    if (step) {
+        cur_step += 1;
+        const int C = A + O;                                            // colliders: agents + obstacles (landmarks collide=False)
+        double* Fx = reinterpret_cast<double*>(l.M);                    // pair forces alias the (not yet built) fp32 matrix
+        double* Fy = Fx + (size_t)G * A * C;
+        if (!kin) {
+            // ---- 1a. contact forces, one PAIR per lane (get_entity_collision_force core.py:872-906): pair (a, k>a)
+            // computed once with delta = pos[a]-pos[k]; side a gets +F, side k gets -F (summed in 1b).
+            const int NP = A * (A - 1) / 2, W = NP + A * O;            // valid pairs only: agent pairs (a<k) + agent x obstacle
+            for (int q = tid; q < Gv * W; q += BLOCK) {
+                const int gg = fdiv(q, W, p.m_FW), w = q - gg * W;
+                int a, kk;
+                if (w < NP) { const int pk = l.ptab[w]; a = pk >> 8; kk = pk & 255; }
+                else { const int t = w - NP; a = fdiv(t, O, p.m_O); kk = A + (t - a * O); }
+                const int k = kk < A ? kk : L + kk;                     // entity index of collider kk
+                const double dx = l.ex[gg * E + a] - l.ex[gg * E + k], dy = l.ey[gg * E + a] - l.ey[gg * E + k];
+                const double dist = sqrt(dx * dx + dy * dy);
+                double fx = 0.0, fy = 0.0;
+                if (dist < c.sep_dist + 50.0 * c.contact_margin) {      // else softplus < 1e-21: below one ulp of the sum
+                    const double pen = logaddexp0(-(dist - c.sep_dist) / c.contact_margin) * c.contact_margin;
+                    fx = c.contact_force * dx / dist * pen; fy = c.contact_force * dy / dist * pen;
+                }
+                Fx[(size_t)gg * A * C + a * C + kk] = fx; Fy[(size_t)gg * A * C + a * C + kk] = fy;
+            }
+            __syncthreads();
+        }
+        STAMP(2);
+        // ---- 1b. action decode + dynamics
+        double nx = 0, ny = 0, nv2 = 0, nv3 = 0;
+        if (ag) {
+            double u0, u1; decode_action<SC>(c, act_idx, u0, u1);
+            nx = v.ex[i]; ny = v.ey[i]; nv2 = v.s2[i]; nv3 = v.s3[i];
+            if (kin) {
+                if (!v.s_old[i]) {                                      // update_agent_state core.py:819-826
+                    const double dt = c.dt, th0 = nv2, v0 = nv3;
+                    const double th1 = th0 + u0 * dt, v1 = v0 + u1 * dt;
+                    if (u0 != 0.0) {
+                        double s0, c0, s1, c1; sincos(th0, &s0, &c0); sincos(th1, &s1, &c1);
+                        nx += (v1 * s1 - v0 * s0) / u0 + u1 * (c1 - c0) / (u0 * u0);
+                        ny += (-v1 * c1 + v0 * c0) / u0 + u1 * (s1 - s0) / (u0 * u0);
+                    } else {
+                        const double d = (v0 + 0.5 * u1 * dt) * dt;
+                        double s0, c0; sincos(th0, &s0, &c0);
+                        nx += d * c0; ny += d * s0;
+                    }
+                    double vv = v1;
+                    if (vv > c.v_max) vv = c.v_max;
+                    if (vv < c.v_min) vv = c.v_min;
+                    nv2 = th1; nv3 = vv;
+                    p_dist += vv * dt; tim += dt;
+                }
+            } else {
+                // force path core.py:766-845: accumulate in the reference's order for this agent — other
+                // entities by ascending index (side b below its own index, side a above), then walls.
+                double sx = 1.0 * u0, sy = 1.0 * u1;
+                const double* fxg = Fx + (size_t)g * A * C; const double* fyg = Fy + (size_t)g * A * C;
+                const bool ego_live = v.s_old[i] == 0;                  // done side gets no agent-agent force (899-900)
+                SWEEP(k, A) {
+                    const bool ok = !AP || k < A;
+                    const int kc = ok ? k : 0;
+                    const bool below = kc < i;
+                    const int idx = below ? kc * C + i : i * C + kc;
+                    const double fx = fxg[idx], fy = fyg[idx];
+                    const bool use = ok && ego_live && kc != i && (fx != 0.0 || fy != 0.0);
+                    sx = use ? ((below ? -fx : fx) + sx) : sx;
+                    sy = use ? ((below ? -fy : fy) + sy) : sy;
+                }
+                for (int o = 0; o < O; ++o) {                           // immovable obstacles push regardless of status
+                    const double fx = fxg[i * C + A + o], fy = fyg[i * C + A + o];
+                    if (fx != 0.0 || fy != 0.0) { sx = fx + sx; sy = fy + sy; }
+                }
+                if (WALLS) for (int w = 0; w < c.num_walls; ++w) {
+                    double wx, wy;
+                    if (wall_force(c.walls[w], nx, ny, c.entity_size, c.wall_contact_force, c.wall_contact_margin, wx, wy)) { sx = sx + wx; sy = sy + wy; }
+                }
+                double vx = nv2 * (1 - c.damping), vy = nv3 * (1 - c.damping);
+                vx += (sx / 1.0) * c.dt; vy += (sy / 1.0) * c.dt;
+                if (c.max_speed > 0) {
+                    const double sp = sqrt(vx * vx + vy * vy);
+                    if (sp > c.max_speed) { vx = vx / sp * c.max_speed; vy = vy / sp * c.max_speed; }
+                }
+                nv2 = vx; nv3 = vy;
+                nx += vx * c.dt; ny += vy * c.dt;
+                const double ax = vx * c.dt, ay = vy * c.dt;
+                p_dist += sqrt(ax * ax + ay * ay); tim += c.dt;
+            }
+            v.ex[i] = nx; v.ey[i] = ny; v.s2[i] = nv2; v.s3[i] = nv3;   // nobody reads positions between 1a and here
+        }
+        __syncthreads();
+        STAMP(3);
+        distance_pass<BLOCK>(p, l, Gv, tid, false);                    // post-move rows: obs, reward, info, adj all read these
+        static_block<BLOCK>(p, l, Gv, tid, false);
+        __syncthreads();
+        STAMP(4);
+
+        // ---- 2. phase FSM + who newly reaches the goal (depends only on own data: SURVEY §8a)
+        prevA = prev_phase;
+        if (ag) {
+            const double px = v.ex[i], py = v.ey[i];
+            double vx, vy; vel_of<SC>(v.s2[i], v.s3[i], vx, vy);
+            v.vox[i] = vx; v.voy[i] = vy;
+            if (july) {
+                ph1 = phase_eval(v.tube, px, py, prev_phase, prevA);     // observation's call (:1447)
+                if (cooldown > 0) cooldown -= 1;
+                int prevB;
+                cp = phase_eval(v.tube, px, py, prevA, prevB);           // reward's call (:1113)
+                if (cooldown > 0) cooldown -= 1;
+                prevA = prevB;
+                goal_branch = (cp == 2 && phase_reached != 0);
+            } else if (rotinv) {
+                // rot_inv.py:675-739: the query mutates only the cooldown, so observation's and reward's calls agree;
+                // phase 2 is only returned with phase_reached >= 1, hence the goal block runs iff cp == 2 (:1281-1297)
+                ph1 = phase_eval_rot(v.tube, px, py, prev_phase, phase_reached);
+                if (cooldown > 0) cooldown -= 1;
+                if (cooldown > 0) cooldown -= 1;
+                cp = ph1;
+                goal_branch = (cp == 2);
+            }
+            dgoal = v.Dm[(size_t)i * E + A + i];
+            v.newf[i] = goal_branch && dgoal < c.goal_thresh && !v.s_old[i];
+        }
+        // rank of each newly-reached agent among its env's: heading re-draws follow agent order (core.py:328)
+        if (tid < 64) {
+            const unsigned long long bal = __ballot(ag && v.newf[i]);
+            if (ag) {
+                if (v.newf[i]) {
+                    const int rank = __popcll(bal & emask & ((1ull << tid) - 1ull));
+                    if (kin) { v.n2[i] = 0.0 + (2 * M_PI - 0.0) * draw_at(c, p.s, n, ctr0 + rank, err); v.n3[i] = c.v_min; }
+                    else { v.n2[i] = 0.0; v.n3[i] = 0.0; }
+                    v.gt[i] = i;
+                    double vx, vy; vel_of<SC>(v.n2[i], v.n3[i], vx, vy);
+                    v.vnx[i] = vx; v.vny[i] = vy;
+                } else { v.n2[i] = v.s2[i]; v.n3[i] = v.s3[i]; v.vnx[i] = v.vox[i]; v.vny[i] = v.voy[i]; }
+                if (rotinv) { double sn_, cn_; sincos(v.n2[i], &sn_, &cn_); v.cn[i] = cn_; v.sn[i] = sn_; }
+                if (i == 0) v.flags[1] = kin ? __popcll(bal & emask) : 0;   // draws consumed (DI reset_velocity draws none)
+                // done flag (_get_done environment.py:264-271) and this step's adjacency mask (…_july.py:1627-1648:
+                // done agents, reached landmarks) depend only on status / goal_tracker: known before the rewards
+                const bool st_now = v.s_old[i] || v.newf[i];
+                done = st_now || cur_step >= c.episode_length;
+                v.moff[i] = st_now ? 1 : 0; v.moff[A + i] = (v.gt[i] == i) ? 1 : 0;
+            }
+            // all agents of an env done -> the worker resets it (env_wrappers.py:865-870)
+            const unsigned long long dbal = __ballot(ag && done);
+            const unsigned long long mbal = __ballot(ag && (v.moff[i] | v.moff[A + i]));
+            all_done = ag && ((dbal & emask) == emask);
+            if (ag && i == 0) { v.flags[0] = all_done; v.flags[2] = (mbal & emask) != 0ull; }
+        }
+        __syncthreads();
+        STAMP(5);
+    }
+
+
+    int any_reset = 0, any_mask = 0;
+    for (int gg = 0; gg < Gv; ++gg) { any_reset |= l.flags[gg * 4 + 0]; any_mask |= l.flags[gg * 4 + 2]; }   // block-uniform
+    const int abl = p.ablate;
+
+
+    // Common case (no env of the tile resets): issue the 22 KB/env of graph stores FIRST, then do the reward /
+    // info arithmetic under the HBM write drain. Tiles with a reset need the terminal reward/info before the
+    // reset overwrites the LDS state, so they keep the reference's order.
+    const bool early = step && !any_reset;
+    // Multi-wave tiles specialise: wave 0 (all agent lanes) does reward / info / write-back while waves 1.. stream the
+    // graph observations, so the ~7 us of per-agent arithmetic runs beside the store issue instead of after it.
+    const bool spec = early && BLOCK > 64 && p.spec;
+    if (early && !spec) stream_graph_fn<BLOCK, AP, SC>(p, l, Gv, n0, tid, tid, BLOCK, true, any_mask);
+    if (spec) {
+        if (any_mask && !(abl & 4)) {
+            for (int q = tid; q < Gv * EE; q += BLOCK) {
+                const int gg = fdiv(q, EE, p.m_EE), rc = q - gg * EE;
+                if (!l.flags[gg * 4 + 2]) continue;
+                const int r = fdiv(rc, E, p.m_E), cc = rc - r * E;
+                if (l.moff[gg * E + r] | l.moff[gg * E + cc]) l.M[(size_t)gg * EE4 + rc] = 0.0f;
+            }
+        }
+        __syncthreads();
+    }
+    if (step) {
+        if (!spec || tid < 64) {
+            // ---- sections 3+4 (obs, reward, info, write-back). In specialised tiles only wave 0 gets here and the
+            // block barrier between the two sections is replaced by wave-local ordering.
+            const bool block_sync = !spec;
+            // ---- 3. obs, reward, done (ego i sees agent k done iff s_old[k] || (new[k] && k < i))
+            rew = 0;
+            if (ag) {
+                const double px = v.ex[i], py = v.ey[i];
+                const double* row = v.Dm + (size_t)i * E;
+                if (rotinv) write_obs_rot<AP>(p, v, i, ph1); else write_obs<AP, SC>(p, v, i, v.vox[i], v.voy[i], ph1);
+                STAMP(13);
+                // collision block (…_july.py:1117-1124) and info_callback's collision count (:780-786) in one sweep
+                int ncol_r = 0, ncol_i = 0;
+                const bool me_old = v.s_old[i] != 0, me_new = v.newf[i] != 0;
+                if (AP) {                                                  // all LDS reads of the sweep first, then the arithmetic
+                    double rv[AP ? AP : 1]; int so[AP ? AP : 1], nf[AP ? AP : 1];
+    #pragma unroll
+                    for (int a = 0; a < AP; ++a) { const int ac = a < A ? a : 0; rv[a] = row[ac]; so[a] = v.s_old[ac]; nf[a] = v.newf[ac]; }
+                    __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                    for (int a = 0; a < AP; ++a) {
+                        const bool close = a < A && rv[a] < c.sep_dist && a != i;
+                        ncol_r += (close && !so[a] && !(nf[a] && a < i)) ? 1 : 0;
+                        ncol_i += (close && !so[a] && !(nf[a] && a <= i)) ? 1 : 0;
+                    }
+                } else {
+                    for (int a = 0; a < A; ++a) {
+                        const bool close = row[a] < c.sep_dist && a != i;
+                        const int so = v.s_old[a], nf = v.newf[a];
+                        ncol_r += (close && !so && !(nf && a < i)) ? 1 : 0;
+                        ncol_i += (close && !so && !(nf && a <= i)) ? 1 : 0;
+                    }
+                }
+                if (me_old) { ncol_r = 0; }
+                if (me_old || me_new) ncol_i = 0;
+                for (int q = 0; q < ncol_r; ++q) rew -= c.collision_rew * 4;
+                nac += ncol_i;
+                STAMP(14);
+                const bool obst_hit = obstacle_collision_ego(p, v, i);
+                if (obst_hit) { rew -= c.collision_rew * 3; noc += 1; }
+                double serr = 0;
+                if (july) {
+                    const double tdx = v.tube[T_EXX] - v.tube[T_ENTX], tdy = v.tube[T_EXY] - v.tube[T_ENTY];
+                    const double tlen = sqrt(tdx * tdx + tdy * tdy);
+                    if (cp == 2 && cp > prevA + 1) rew -= c.goal_rew * 3;
+                    const double ux = tdx / tlen, uy = tdy / tlen;
+                    const double qx = px - v.tube[T_ENTX], qy = py - v.tube[T_ENTY];
+                    const double proj = qx * ux + qy * uy;
+                    if (cp == prevA + 1 && phase_reached == cp - 1) {
+                        if (cp == 1) {
+                            const double edist = norm2(qx - proj * tdx, qy - proj * tdy);   // un-normalised (:1154)
+                            if (0 <= proj && proj < 0.1 * tlen && edist < 0.2 * tlen) rew += c.goal_rew * 3;
+                        } else if (cp == 2) rew += c.goal_rew * 3;
+                    }
+                    if (cp == 0) rew -= norm2(v.tube[T_ENTX] - px, v.tube[T_ENTY] - py);
+                    else if (cp == 1) {
+                        double hx, hy; sincos(v.s2[i], &hy, &hx);
+                        int front = -1, back = -1; double fproj = 0, bproj = 0;
+                        for (int k = 0; k < A; ++k) {                       // 1136-1143, first wins ties
+                            if (k == i) continue;
+                            const double pj = (v.ex[k] - px) * hx + (v.ey[k] - py) * hy;
+                            if (pj > 0) { if (front < 0 || pj < fproj) { front = k; fproj = pj; } }
+                            else { if (back < 0 || pj > bproj) { back = k; bproj = pj; } }
+                        }
+                        if (front >= 0) { const double df = row[front] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
+                        if (back >= 0) { const double df = row[back] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
+                        if (serr > 0) sv += 1;
+                        rew -= serr * c.formation_rew;
+                        rew -= norm2(v.tube[T_EXX] - px, v.tube[T_EXY] - py);
+                        sic += 1;
+                    } else if (cp == 2 && phase_reached == 0) cp = 0;
+                    else {
+                        if (dgoal < c.goal_thresh) { if (me_new) rew += c.goal_rew * 5; }
+                        else rew -= dgoal;
+                    }
+                    if (phase_reached == 1 && cp == 0) conf += 1;
+                    if (cp > phase_reached) phase_reached = cp;
+                    if (cp < prevA) rew -= c.collision_rew * 3;
+                    if (cp < phase_reached) rew -= c.collision_rew;
+                    prev_phase = cp;
+                } else if (rotinv) {
+                    // Scenario.reward, rot_inv.py:1122-1338
+                    const double Lt = v.tube[T_L], hw = v.tube[T_HALFW];
+                    double ts, ty; tube_sy(v.tube, px, py, ts, ty);
+                    if (cp == 2 && cp > prev_phase + 1) rew -= c.goal_rew;
+                    if (cp == prev_phase + 1 && phase_reached == cp - 1) {
+                        if (cp == 1 && in_entrance_gate(ts, ty, Lt, hw) && cooldown == 0) {
+                            rew += c.goal_rew;
+                            cooldown = (int)((double)c.episode_length / 10);       // float into an int32 array (:1200, :228)
+                            phase_reached = 1;
+                        } else if (cp == 2) { rew += c.goal_rew; phase_reached = 2; }
+                    }
+                    if (cp == 0) rew -= entrance_gate_distance(ts, ty, hw);
+                    else if (cp == 1) {
+                        const double tdx = v.tube[T_EXX] - v.tube[T_ENTX], tdy = v.tube[T_EXY] - v.tube[T_ENTY];
+                        const double tlen = sqrt(tdx * tdx + tdy * tdy);
+                        const double proj = (px - v.tube[T_ENTX]) * (tdx / tlen) + (py - v.tube[T_ENTY]) * (tdy / tlen);
+                        double hx, hy; sincos(v.s2[i], &hy, &hx);
+                        int front = -1, back = -1; double fproj = 0, bproj = 0;
+                        for (int k = 0; k < A; ++k) {
+                            if (k == i) continue;
+                            const double pj = (v.ex[k] - px) * hx + (v.ey[k] - py) * hy;
+                            if (pj > 0) { if (front < 0 || pj < fproj) { front = k; fproj = pj; } }
+                            else { if (back < 0 || pj > bproj) { back = k; bproj = pj; } }
+                        }
+                        if (front >= 0) { const double df = row[front] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
+                        if (back >= 0) { const double df = row[back] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
+                        if (serr > 0) sv += 1;
+                        rew -= serr * c.formation_rew;
+                        rew -= exit_gate_distance(ts, ty, Lt, hw);
+                        const double gain = c.goal_rew / (c.world_size * 0.8 * 10);             // :522
+                        const double dproj = proj - pproj;
+                        rew += gain * (dproj > -0.05 ? dproj : -0.05);
+                        sic += 1;
+                        pproj = (double)(float)proj;                                           // float32 array (:374)
+                    } else if (cp == 2 && phase_reached == 0) cp = 0;
+                    else if (cp == 2) {
+                        if (dgoal < c.goal_thresh) { if (me_new) rew += c.goal_rew * 5; }
+                        else rew -= dgoal;
+                    }
+                    if (phase_reached == 1 && cp == 0) conf += 1;
+                    if (cp > phase_reached) phase_reached = cp;
+                    if (cp < prev_phase) rew -= c.collision_rew;
+                    if (cp < phase_reached) rew -= c.collision_rew;
+                    prev_phase = cp;
+                    if (in_tube_rect(ts, ty, Lt, hw) && cp != 1) rew -= c.collision_rew;
+                    if (ts > Lt && phase_reached < 1) rew -= c.goal_rew;
+                } else {
+                    if (dgoal < c.goal_thresh) { if (me_new) rew += c.goal_rew * 5; }
+                    else rew -= dgoal;
+                }
+                rew = clipd(rew, -4 * c.collision_rew, c.goal_rew * 5);
+                if (!rotinv) rew = clipd(rew, c.min_reward, c.max_reward);                      // rot_inv.py:1338 clips once
+                v.serr[i] = serr; v.rew[i] = rew;
+
+                STAMP(15);
+                // ---- info counters that depend on own data only (…_july.py:744-773)
+                v.dtg_o[i] = dtg; v.trq_o[i] = trq;
+                int nearest = 0; double dmin = INF;
+                SWEEP(q, L) { const bool ok = !AP || q < L; const double d = ok ? row[A + (ok ? q : 0)] : INF; const bool lt = d < dmin; dmin = lt ? d : dmin; nearest = lt ? q : nearest; }
+                const double thr = c.goal_thresh;
+                const int tnow = (int)((double)cur_step * c.dt);
+                if (dmin < thr && (nearest != greached && greached != -1)) { greached = nearest; dleft = (int)dmin; }
+                if (dmin < thr && trq == -1) { trq = tnow; dtg = (int)p_dist; dleft = (int)dmin; greached = nearest; }
+                if (trq == -1) { dtg = (int)p_dist; dleft = (int)dmin; }
+                if (dmin > thr && trq != -1) { dtg = (int)p_dist; trq = tnow; dleft = (int)dmin; }
+                if (dmin < thr && nearest == greached) { dleft = (int)dmin; greached = nearest; }
+                v.dtg_n[i] = dtg; v.trq_n[i] = trq;
+                v.sv_n[i] = sv; v.sv_o[i] = sv - (serr > 0 ? 1 : 0);
+            }
+            if (block_sync) __syncthreads();
+            else {                                                          // every agent lane lives in wave 0: LDS ops of one wave are
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // executed in order, the fences only pin the compiler's order
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            STAMP(6);
+
+            // ---- 4. info (sequential view: agents j<=i already updated, j>i not yet), outputs, write-back
+            if (ag) {
+                double rsum = 0;
+                if (c.collaborative) for (int a = 0; a < A; ++a) rsum += v.rew[a];
+                if (p.o.reward) p.o.reward[na] = (float)(c.collaborative ? rsum : rew);
+                if (p.o.done) p.o.done[na] = done ? 1 : 0;
+                if (p.o.info) {
+                    // the counters are small integers: their sums and sums of squares are exact in fp64 in any order
+                    double sd = 0, st = 0, sdd = 0, stt = 0; int ssv = 0;
+                    SWEEP(a, A) {
+                        const bool ok = !AP || a < A;
+                        const int ac = ok ? a : 0;
+                        const bool nw = ac <= i;
+                        const int dn = v.dtg_n[ac], d_o = v.dtg_o[ac], tn = v.trq_n[ac], to = v.trq_o[ac], svn = v.sv_n[ac], svo = v.sv_o[ac];
+                        const double dd = ok ? (double)(nw ? dn : d_o) : 0.0, tt = ok ? (double)(nw ? tn : to) : 0.0;
+                        sd += dd; st += tt; sdd += dd * dd; stt += tt * tt;
+                        ssv += ok ? (nw ? svn : svo) : 0;
+                    }
+                    double dsp = dsp0;
+                    if (july || rotinv) for (int a = 0; a <= i; ++a) dsp += v.serr[a];   // same order as the list append (:1180)
+                    const double dm = sd / A, tm = st / A;
+                    // population variance = (A*sum(x^2) - sum(x)^2) / A^2, numerator exact
+                    const double dvn = (double)A * sdd - sd * sd, tvn = (double)A * stt - st * st;
+                    const double ds = sqrt(dvn) / A, ts = sqrt(tvn) / A;
+                    float* o = p.o.info + na * GMPE_INFO_KEYS;
+                    o[0] = (float)rew; o[1] = (float)dleft; o[2] = (float)trq; o[3] = (float)nac; o[4] = (float)noc;
+                    o[5] = (float)dm; o[6] = (float)ds; o[7] = (float)(dm / (ds + 0.0001)); o[8] = (float)dtg;
+                    o[9] = (float)trq; o[10] = (float)tm; o[11] = (float)ts; o[12] = (float)(tm / (ts + 0.0001));
+                    o[13] = (float)((double)conf / c.episode_length);
+                    o[14] = (float)(dsp / (ssv != 0 ? (double)ssv : 1.0));
+                    o[15] = (float)((double)sv / (sic != 0 ? sic : 1));
+                    o[16] = (float)gmt;
+                    o[17] = (float)phase_reached;
+                }
+                if (!all_done) {                                            // persist the stepped state
+                    if (i == 0) {
+                        double dsp = dsp0;
+                        if (july || rotinv) for (int a = 0; a < A; ++a) dsp += v.serr[a];
+                        p.s.delta_spacing[n] = dsp;
+                        p.s.rng_ctr[n] = ctr0 + v.flags[1];
+                        p.s.current_step[n] = cur_step;
+                    }
+                    p.s.x[na] = v.ex[i]; p.s.y[na] = v.ey[i]; p.s.s2[na] = v.n2[i]; p.s.s3[na] = v.n3[i];
+                    p.s.status[na] = (uint8_t)(v.s_old[i] || v.newf[i]);
+                    p.s.prev_phase[na] = prev_phase; p.s.phase_reached[na] = phase_reached; p.s.cooldown[na] = cooldown;
+                    p.s.goal_tracker[na] = v.gt[i]; p.s.p_dist[na] = p_dist; p.s.time[na] = tim;
+                    p.s.times_required[na] = trq; p.s.dists_to_goal[na] = dtg; p.s.dist_left[na] = dleft;
+                    p.s.goal_reached[na] = greached; p.s.n_agent_coll[na] = nac; p.s.n_obst_coll[na] = noc;
+                    p.s.spacing_viol[na] = sv; p.s.steps_in_corr[na] = sic; p.s.conformance[na] = conf;
+                    if (rotinv) p.s.prev_proj[na] = pproj;
+                }
+            }
+            STAMP(7);
+            if (spec) {                                                 // wave-local: the rows were written by this wave's own lanes
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (p.o.obs) {
+                    float* dst = p.o.obs + (size_t)n0 * A * D;
+                    const int AD = A * D;
+                    for (int q = tid; q < Gv * AD; q += 64) { const int gg = fdiv(q, AD, p.m_AD); if (l.flags[gg * 4 + 3]) dst[q] = l.obs[(size_t)gg * AD4 + (q - gg * AD)]; }
+                }
+                if (p.o.agent_id) for (int q = tid; q < Gv * A; q += 64) { const int gg = fdiv(q, A, p.m_A); if (l.flags[gg * 4 + 3]) p.o.agent_id[(size_t)n0 * A + q] = q - gg * A; }
+            }
+        }
+        else stream_graph_fn<BLOCK, AP, SC>(p, l, Gv, n0, tid, tid - 64, BLOCK - 64, false, any_mask);
+        __syncthreads();
+    }
+    {
+        // ---- 5. reset (explicit, or the worker's auto-reset when every agent of the env is done)
+        if (any_reset) {
+            const bool mine = ag && v.flags[0];
+            if (mine && i == 0) {                                             // one lane per resetting env
+                int64_t ctr = ctr0 + (step ? v.flags[1] : 0);                // this step's heading re-draws come first
+                reset_world_serial<SC>(p, v, n, ctr, err);
+                p.s.rng_ctr[n] = ctr;
+                p.s.current_step[n] = 0;
+                p.s.delta_spacing[n] = 0.0;
+                v.flags[2] = 0;
+            }
+            __syncthreads();
+            if (mine) {
+                v.s2[i] = v.n2[i]; v.s3[i] = v.n3[i];
+                double vx, vy; vel_of<SC>(v.n2[i], v.n3[i], vx, vy);
+                v.vox[i] = v.vnx[i] = vx; v.voy[i] = v.vny[i] = vy;
+                v.s_old[i] = 0; v.newf[i] = 0; v.gt[i] = -1; v.moff[i] = 0; v.moff[A + i] = 0;
+                int prevA = prev_phase, ph = 0;
+                if (july) ph = phase_eval(v.tube, v.ex[i], v.ey[i], prev_phase, prevA);   // reset-time observation (:1447)
+                prev_phase = prevA;
+                if (rotinv) { ph = phase_eval_rot(v.tube, v.ex[i], v.ey[i], prev_phase, 0); double sn_, cn_; sincos(v.n2[i], &sn_, &cn_); v.cn[i] = cn_; v.sn[i] = sn_; p.s.prev_proj[na] = 0.0; }
+                const double dx = v.ex[i] - v.ex[A + i], dy = v.ey[i] - v.ey[A + i];
+                gmt = c.max_speed > 0 ? sqrt(dx * dx + dy * dy) / c.max_speed : 0.0;
+                p.s.x[na] = v.ex[i]; p.s.y[na] = v.ey[i]; p.s.s2[na] = v.n2[i]; p.s.s3[na] = v.n3[i];
+                p.s.status[na] = 0; p.s.prev_phase[na] = prev_phase; p.s.phase_reached[na] = 0; p.s.cooldown[na] = 0;
+                p.s.goal_tracker[na] = -1; p.s.p_dist[na] = 0.0; p.s.time[na] = 0.0;
+                p.s.times_required[na] = -1; p.s.dists_to_goal[na] = -1; p.s.dist_left[na] = -1;
+                p.s.goal_reached[na] = -1; p.s.n_agent_coll[na] = 0; p.s.n_obst_coll[na] = 0;
+                p.s.spacing_viol[na] = 0; p.s.steps_in_corr[na] = 0; p.s.conformance[na] = 0;
+                p.s.goal_min_time[na] = gmt;
+                ph1 = ph;
+            }
+            __syncthreads();                                                // positions of all agents final
+            distance_pass<BLOCK>(p, l, Gv, tid, true);
+            static_block<BLOCK>(p, l, Gv, tid, true);
+            __syncthreads();
+            if (mine) { if (rotinv) write_obs_rot<AP>(p, v, i, ph1); else write_obs<AP, SC>(p, v, i, v.vox[i], v.voy[i], ph1); }
+            any_mask = 0;
+            for (int gg = 0; gg < Gv; ++gg) any_mask |= l.flags[gg * 4 + 2];
+        }
+        STAMP(8);
+    }
+    if (!early) stream_graph_fn<BLOCK, AP, SC>(p, l, Gv, n0, tid, tid, BLOCK, true, any_mask);
+    // ---- small outputs: obs staging rows and agent ids. In a specialised tile wave 0 has already stored them
+    // (it wrote the staging rows itself), so nobody waits behind the barrier for the streaming waves.
+    STAMP(11);
+    if (!spec) {
+        if (p.o.obs) {
+            float* dst = p.o.obs + (size_t)n0 * A * D;
+            const int AD = A * D;
+            for (int q = tid; q < Gv * AD; q += BLOCK) { const int gg = fdiv(q, AD, p.m_AD); if (l.flags[gg * 4 + 3]) dst[q] = l.obs[(size_t)gg * AD4 + (q - gg * AD)]; }
+        }
+        if (p.o.agent_id) for (int q = tid; q < Gv * A; q += BLOCK) { const int gg = fdiv(q, A, p.m_A); if (l.flags[gg * 4 + 3]) p.o.agent_id[(size_t)n0 * A + q] = q - gg * A; }   // get_id :1554
+    }
+    if (ag && err) atomicOr(&p.s.error_flags[n], err);
+    STAMP(12);
+}
+
+
+// Host entry points of one scenario variant; defined and explicitly instantiated in gmpe_sc.hip (-DGMPE_SC=k).
+template <int SC> void launch_env(int block, int ap, dim3 grid, size_t lds, hipStream_t st, const KParams& p);
+template <int SC> hipError_t set_max_lds(int lds);
+
+}  // namespace gmpe

@@ -1,0 +1,40 @@
+// gmpe_sc.hip — one scenario variant of the fused kernel per translation unit (compiled with -DGMPE_SC=<variant>, in
+// parallel): tile shapes BLOCK in {64,128,256} x exact-size instantiations AP in {0,3,10}.
+#include "gmpe_kernel.h"
+
+#ifndef GMPE_SC
+#error "compile with -DGMPE_SC=<scenario variant>"
+#endif
+
+namespace gmpe {
+
+template <int SC>
+void launch_env(int block, int ap, dim3 grid, size_t lds, hipStream_t st, const KParams& p) {
+#define LAUNCH_ENV(B) do { \
+        if (ap == 10) hipLaunchKernelGGL((k_env<B, 10, SC>), grid, dim3(B), lds, st, p); \
+        else if (ap == 3) hipLaunchKernelGGL((k_env<B, 3, SC>), grid, dim3(B), lds, st, p); \
+        else hipLaunchKernelGGL((k_env<B, 0, SC>), grid, dim3(B), lds, st, p); \
+    } while (0)
+    switch (block) {
+        case 64: LAUNCH_ENV(64); break;
+        case 128: LAUNCH_ENV(128); break;
+        default: LAUNCH_ENV(256); break;
+    }
+#undef LAUNCH_ENV
+}
+
+// opt in to > 64 KiB of dynamic LDS (gfx950: 160 KiB per CU)
+template <int SC>
+hipError_t set_max_lds(int lds) {
+#define FN(B, P) reinterpret_cast<const void*>(&k_env<B, P, SC>)
+    const void* fns[9] = {FN(64, 0), FN(64, 3), FN(64, 10), FN(128, 0), FN(128, 3), FN(128, 10), FN(256, 0), FN(256, 3), FN(256, 10)};
+#undef FN
+    hipError_t e = hipSuccess;
+    for (int q = 0; q < 9 && e == hipSuccess; ++q) e = hipFuncSetAttribute(fns[q], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return e;
+}
+
+template void launch_env<GMPE_SC>(int, int, dim3, size_t, hipStream_t, const KParams&);
+template hipError_t set_max_lds<GMPE_SC>(int);
+
+}  // namespace gmpe
