@@ -21,10 +21,15 @@ TUBE_STRIDE = 12
 SCENARIO_NAVIGATION_GRAPH = 0
 SCENARIO_TUBE_JULY = 1
 SCENARIO_ROT_INV = 2
+SCENARIO_TWO_PHASE = 3
+SCENARIO_THREE_PHASE = 4
+ROT_FAMILY = (SCENARIO_ROT_INV, SCENARIO_TWO_PHASE, SCENARIO_THREE_PHASE)      # rotated-frame float32 features, F = 7
 SCENARIOS = {
     "navigation_graph": SCENARIO_NAVIGATION_GRAPH,
     "nav_metered_one_goal_graph_rotate_tube_july": SCENARIO_TUBE_JULY,
     "nav_graph_metered_single_corridor_rot_inv": SCENARIO_ROT_INV,
+    "two_phase_graph": SCENARIO_TWO_PHASE,
+    "three_phase_graph": SCENARIO_THREE_PHASE,
 }
 DYN_DOUBLE_INTEGRATOR, DYN_UNICYCLE, DYN_AIR_TAXI = 0, 1, 2
 DYNAMICS = {"double_integrator": DYN_DOUBLE_INTEGRATOR, "unicycle_vehicle": DYN_UNICYCLE,
@@ -103,11 +108,11 @@ class GmpeConfig(C.Structure):
 
     @property
     def obs_dim(self):
-        return 19 if self.scenario == SCENARIO_TUBE_JULY else 13
+        return 19 if self.scenario == SCENARIO_TUBE_JULY else (15 if self.scenario in (SCENARIO_TWO_PHASE, SCENARIO_THREE_PHASE) else 13)
 
     @property
     def node_feats(self):
-        return 7 if self.scenario == SCENARIO_ROT_INV else NODE_FEATS
+        return 7 if self.scenario in ROT_FAMILY else NODE_FEATS
 
 
 def default_walls(world_size, num_walls):

@@ -54,8 +54,11 @@ typedef enum gmpe_scenario {
     GMPE_SCENARIO_NAVIGATION_GRAPH = 0, /* not shipped by the reference (train_mpe.py:72-73 default only):
                                            restated from extant blocks, see DESIGN.md §navigation_graph */
     GMPE_SCENARIO_TUBE_JULY = 1,        /* nav_metered_one_goal_graph_rotate_tube_july.py               */
-    GMPE_SCENARIO_ROT_INV = 2           /* nav_graph_metered_single_corridor_rot_inv.py: rotation-
+    GMPE_SCENARIO_ROT_INV = 2,          /* nav_graph_metered_single_corridor_rot_inv.py: rotation-
                                            invariant 13-d obs, 7 node features, exit gate + progress reward, armed cooldown */
+    GMPE_SCENARIO_TWO_PHASE = 3,        /* two_phase_graph.py: rot_inv family, 15-d obs (exit vector, heading alignment), random
+                                           tube length, episode ends for an agent at the exit gate, no collision reward term  */
+    GMPE_SCENARIO_THREE_PHASE = 4       /* three_phase_graph.py: two_phase + post-tube goal phase, -collision_rew per contact   */
 } gmpe_scenario;
 
 /* Dynamics (multiagent/core.py:23-26 EntityDynamicsType). */

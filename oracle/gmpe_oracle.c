@@ -95,8 +95,10 @@ static inline double logaddexp0(double x) {
 }
 static inline int is_kinematic(const gmpo* h) { return h->c.dynamics != GMPE_DYN_DOUBLE_INTEGRATOR; }
 
-int gmpo_obs_dim(const gmpe_config* c) { return c->scenario == GMPE_SCENARIO_TUBE_JULY ? 19 : 13; }
-int gmpo_node_feats(const gmpe_config* c) { return c->scenario == GMPE_SCENARIO_ROT_INV ? 7 : 8; }
+static inline int is_rotfam(const gmpe_config* c) { return c->scenario >= GMPE_SCENARIO_ROT_INV; }      /* rot_inv, two_phase, three_phase */
+static inline int is_phasefam(const gmpe_config* c) { return c->scenario == GMPE_SCENARIO_TWO_PHASE || c->scenario == GMPE_SCENARIO_THREE_PHASE; }
+int gmpo_obs_dim(const gmpe_config* c) { return c->scenario == GMPE_SCENARIO_TUBE_JULY ? 19 : (is_phasefam(c) ? 15 : 13); }
+int gmpo_node_feats(const gmpe_config* c) { return is_rotfam(c) ? 7 : 8; }
 static inline int is_tube(const gmpe_config* c) { return c->scenario != GMPE_SCENARIO_NAVIGATION_GRAPH; }
 int gmpo_num_entities(const gmpe_config* c) { return c->num_agents + c->num_landmarks + c->num_obstacles; }
 
@@ -420,19 +422,25 @@ static int in_entrance_gate(double s, double y, double L, double hw) {
     const double eps = 0.05, gf = 0.08 * L, gb = 0.02 * L;
     return (-gb - eps <= s && s <= gf + eps) && (fabs(y) <= hw + eps);
 }
-static int in_exit_gate(double s, double y, double L, double hw) {            /* :654-658 */
-    const double eps = 0.05, eb = 0.05 * L, ef = 0.08 * L;
+static int in_exit_gate(double s, double y, double L, double hw, double back_ratio) {   /* :654-658; exit_back_ratio 0.05 (rot_inv:619) / 0.02 (two_phase_graph.py:589) */
+    const double eps = 0.05, eb = back_ratio * L, ef = 0.08 * L;
     return (L - eb - eps <= s && s <= L + ef + eps) && (fabs(y) <= hw + eps);
 }
 /* rot_inv get_agent_phase: mutates only the cooldown; depends on previous_phase AND phase_reached. */
 static int get_agent_phase_rot(envv* v, int i) {
+    const gmpe_config* c = &v->h->c;
     const double L = v->tube[T_L], hw = v->tube[T_HALFW];
     double s, yy; tube_coords(v, v->x[i], v->y[i], &s, &yy);
     const int in_tube = in_tube_rect(s, yy, L, hw), passed = s > L;
-    const int valid_entrance = in_entrance_gate(s, yy, L, hw), valid_exit = in_exit_gate(s, yy, L, hw);
+    const int valid_entrance = in_entrance_gate(s, yy, L, hw), valid_exit = in_exit_gate(s, yy, L, hw, is_phasefam(c) ? 0.02 : 0.05);
     if (v->cooldown[i] > 0) v->cooldown[i] -= 1;
     if (!in_tube && !passed) return 0;
-    else if (in_tube) { if (v->prev_phase[i] == 0) return valid_entrance ? 1 : 0; return 1; }
+    else if (in_tube) {
+        if (v->prev_phase[i] == 0) return valid_entrance ? 1 : 0;
+        if (is_phasefam(c) && v->prev_phase[i] == 1 && valid_exit) return 2;                       /* two_phase_graph.py:679-685 */
+        if (c->scenario == GMPE_SCENARIO_THREE_PHASE && v->prev_phase[i] == 2 && valid_exit) return 2;  /* three_phase_graph.py:681-683 */
+        return 1;
+    }
     if (passed) {
         if (v->phase_reached[i] >= 1) {
             if (v->prev_phase[i] == 1 && valid_exit) return 2;
@@ -449,13 +457,28 @@ static void rotate(double th, double vx, double vy, double* ox, double* oy) {
 }
 #define F32(x) ((double)(float)(x))
 /* Scenario.observation, …rot_inv.py:1453-1548 — 13 floats, every entry rounded to float32 like the reference. */
+/* np.float64 % float (npy_divmod): fmod, then the sign of the divisor */
+static double pymod(double a, double b) {
+    double m = fmod(a, b);
+    if (m != 0.0) { if ((b < 0) != (m < 0)) m += b; } else m = copysign(0.0, b);
+    return m;
+}
+/* (theta - corridor_heading + pi) % 2pi - pi with corridor_heading = arctan2(e[1], e[0]) (two_phase_graph.py:1060-1063, 1213-1215) */
+static double heading_error_signed(const envv* v, double th) {
+    const double ch = atan2(v->tube[T_EY], v->tube[T_EX]);
+    return pymod(th - ch + M_PI, 2 * M_PI) - M_PI;
+}
 static void observation_rot(envv* v, int i, double* o) {
-    const int A = v->A;
+    const gmpe_config* c = &v->h->c;
+    const int A = v->A, phasefam = is_phasefam(c);
     const double px = v->x[i], py = v->y[i], th = v->s2[i];
-    double gx, gy; rotate(th, v->lm[2 * i] - px, v->lm[2 * i + 1] - py, &gx, &gy);
+    double gx, gy;
+    if (c->scenario == GMPE_SCENARIO_TWO_PHASE) rotate(th, F32(v->tube[T_EXX]) - px, F32(v->tube[T_EXY]) - py, &gx, &gy);   /* float32(exit) - pos (two_phase_graph.py:1196-1198) */
+    else rotate(th, v->lm[2 * i] - px, v->lm[2 * i + 1] - py, &gx, &gy);
     int b1 = -1, b2 = -1; double d1 = 0, d2 = 0;
     for (int k = 0; k < A; ++k) {
         if (k == i) continue;
+        if (phasefam && v->status[k]) continue;                    /* completed agents are "ghosts" (two_phase_graph.py:1174-1176) */
         const double d = norm2(v->x[k] - px, v->y[k] - py);
         if (b1 < 0 || d < d1) { b2 = b1; d2 = d1; b1 = k; d1 = d; }
         else if (b2 < 0 || d < d2) { b2 = k; d2 = d; }
@@ -469,19 +492,24 @@ static void observation_rot(envv* v, int i, double* o) {
     o[0] = F32(cos(th)); o[1] = F32(sin(th)); o[2] = F32(v->s3[i]);
     o[3] = F32(gx); o[4] = F32(gy); o[5] = F32(n1x); o[6] = F32(n1y); o[7] = F32(n2x); o[8] = F32(n2y);
     o[9] = F32(clipd(s / L, -2.0, 2.0)); o[10] = F32(clipd(yy / (hw + 1e-9), -2.0, 2.0));
-    o[11] = F32(exit_gate_distance(s, yy, L, hw) / (L + 1e-9)); o[12] = (double)phase;
+    o[11] = F32(exit_gate_distance(s, yy, L, hw) / (L + 1e-9));
+    if (phasefam) { const double he = heading_error_signed(v, th); o[12] = F32(cos(he)); o[13] = F32(sin(he)); o[14] = (double)phase; }
+    else o[12] = (double)phase;
 }
 /* Scenario.reward, …rot_inv.py:1122-1338 */
 static double reward_rot(envv* v, int i) {
     const gmpe_config* c = &v->h->c;
     const int A = v->A;
     double rew = 0;
+    const int sc = c->scenario, two = sc == GMPE_SCENARIO_TWO_PHASE, three = sc == GMPE_SCENARIO_THREE_PHASE;
     int cp = get_agent_phase_rot(v, i);
-    rew += collision_block(v, i);
+    if (sc == GMPE_SCENARIO_ROT_INV) rew += collision_block(v, i);
+    else if (three) { for (int a = 0; a < A; ++a) { if (a == i) continue; if (is_collision(v, a, i)) rew -= c->collision_rew; } }   /* three_phase_graph.py:965-970; two_phase: none */
     const double tdx = v->tube[T_EXX] - v->tube[T_ENTX], tdy = v->tube[T_EXY] - v->tube[T_ENTY];
     const double tlen = sqrt(tdx * tdx + tdy * tdy);
     const double px = v->x[i], py = v->y[i];
-    const double hx = cos(v->s2[i]), hy = sin(v->s2[i]);
+    const double th_pre = v->s2[i];
+    const double hx = cos(th_pre), hy = sin(th_pre);
     const double L = v->tube[T_L], hw = v->tube[T_HALFW];
     double s, yy; tube_coords(v, px, py, &s, &yy);
     int front = -1, back = -1; double fproj = 0, bproj = 0;
@@ -497,11 +525,23 @@ static double reward_rot(envv* v, int i) {
     if (cp == v->prev_phase[i] + 1 && v->phase_reached[i] == cp - 1) {
         if (cp == 1 && in_entrance_gate(s, yy, L, hw) && v->cooldown[i] == 0) {
             rew += c->goal_rew;
-            v->cooldown[i] = (int32_t)((double)c->episode_length / 10);       /* float assigned into an int32 array (:1200, :228) */
+            v->cooldown[i] = (two || three) ? c->episode_length : (int32_t)((double)c->episode_length / 10);   /* float assigned into an int32 array (:1200, :228); two_phase_graph.py:228 */
             v->phase_reached[i] = 1;
-        } else if (cp == 2) { rew += c->goal_rew; v->phase_reached[i] = 2; }
+        } else if (cp == 2) {
+            rew += c->goal_rew; v->phase_reached[i] = 2;
+            if (two && !v->status[i]) {                                      /* two_phase_graph.py:1040-1044: the episode ends for this agent at the exit gate */
+                v->status[i] = 1;
+                v->s2[i] = uniform(v->h, v->n, 0.0, 2 * M_PI); v->s3[i] = c->v_min;
+                rew += c->goal_rew * 5;
+            }
+        }
     }
-    if (cp == 0) rew -= entrance_gate_distance(s, yy, hw);
+    const double herr = fabs(heading_error_signed(v, th_pre));               /* pre-reward heading (read at :984 before any redraw) */
+    if (cp == 0) {
+        const double de = entrance_gate_distance(s, yy, hw);
+        rew -= de;
+        if ((two || three) && de < c->world_size * 0.1) rew -= herr * c->formation_rew * 0.5;   /* two_phase_graph.py:1057-1067 */
+    }
     else if (cp == 1) {
         double err = 0;
         if (front >= 0) { const double diff = norm2(v->x[front] - px, v->y[front] - py) - c->sep_dist; err += diff < 0 ? fabs(diff) : 0; }
@@ -509,20 +549,29 @@ static double reward_rot(envv* v, int i) {
         if (err > 0) v->spacing_viol[i] += 1;
         rew -= err * c->formation_rew;
         rew -= exit_gate_distance(s, yy, L, hw);
-        const double progress_gain = c->goal_rew / (c->world_size * 0.8 * 10);   /* :522 goal_rew / (tube_length*10) */
-        const double dproj = proj - v->prev_proj[i];
-        rew += progress_gain * (dproj > -0.05 ? dproj : -0.05);
-        v->h->delta_spacing[v->n] += err;
+        if (!(two || three)) {
+            const double progress_gain = c->goal_rew / (c->world_size * 0.8 * 10);   /* :522 goal_rew / (tube_length*10) */
+            const double dproj = proj - v->prev_proj[i];
+            rew += progress_gain * (dproj > -0.05 ? dproj : -0.05);
+            v->prev_proj[i] = F32(proj);                                        /* prev_proj is a float32 array (:374) */
+        } else rew -= herr * c->formation_rew * 0.1;                            /* two_phase_graph.py:1101-1106 */
+        if (!two) v->h->delta_spacing[v->n] += err;                             /* two_phase_graph.py never appends (its Delta_spacing is 0) */
         v->steps_in_corr[i] += 1;
-        v->prev_proj[i] = F32(proj);                                            /* prev_proj is a float32 array (:374) */
-    } else if (cp == 2 && v->phase_reached[i] == 0) cp = 0;
-    else if (cp == 2) rew += goal_block(v, i);
+    } else if (!(two || three) && cp == 2 && v->phase_reached[i] == 0) cp = 0;
+    else if (cp == 2 && !two) {
+        if (three) {                                                            /* three_phase_graph.py:1110-1123: as goal_block, but goal_tracker stays untouched */
+            const double d = norm2(px - v->lm[2 * i], py - v->lm[2 * i + 1]);
+            if (d < c->goal_thresh) {
+                if (!v->status[i]) { v->status[i] = 1; v->s2[i] = uniform(v->h, v->n, 0.0, 2 * M_PI); v->s3[i] = c->v_min; rew += c->goal_rew * 5; }
+            } else rew -= d;
+        } else rew += goal_block(v, i);
+    }
     if (v->phase_reached[i] == 1 && cp == 0) v->conformance[i] += 1;
     if (cp > v->phase_reached[i]) v->phase_reached[i] = cp;
     if (cp < v->prev_phase[i]) rew -= c->collision_rew;
     if (cp < v->phase_reached[i]) rew -= c->collision_rew;
     v->prev_phase[i] = cp;
-    if (in_tube_rect(s, yy, L, hw) && cp != 1) rew -= c->collision_rew;
+    if (in_tube_rect(s, yy, L, hw) && cp != 1 && !(three && in_exit_gate(s, yy, L, hw, 0.02))) rew -= c->collision_rew;   /* three_phase_graph.py:1145 */
     if (s > L && v->phase_reached[i] < 1) rew -= c->goal_rew;
     return clipd(rew, -4 * c->collision_rew, c->goal_rew * 5);
 }
@@ -542,7 +591,8 @@ static void node_features_rot(envv* v, int i, double* node) {
         rotate(th, (double)rvx, (double)rvy, &ox, &oy); r[0] = F32(ox); r[1] = F32(oy);
         rotate(th, (double)rpx, (double)rpy, &ox, &oy); r[2] = F32(ox); r[3] = F32(oy);
         if (k < A) {
-            const float gx = (float)v->lm[2 * k] - apx, gy = (float)v->lm[2 * k + 1] - apy;
+            const int two = v->h->c.scenario == GMPE_SCENARIO_TWO_PHASE;          /* two_phase_graph.py:1405: every agent's goal node feature is the corridor exit */
+            const float gx = (float)(two ? v->tube[T_EXX] : v->lm[2 * k]) - apx, gy = (float)(two ? v->tube[T_EXY] : v->lm[2 * k + 1]) - apy;
             rotate(th, (double)gx, (double)gy, &ox, &oy); r[4] = F32(ox); r[5] = F32(oy); r[6] = 0.0;
         } else { r[4] = r[2]; r[5] = r[3]; r[6] = k < A + L ? 1.0 : 2.0; }
     }
@@ -660,7 +710,7 @@ static double reward_nav(envv* v, int i) {
  * node: [E,8] for ego i. The adjacency is world.cached_dist_mag itself, masked IN PLACE. */
 static void graph_observation(envv* v, int i, double* node) {
     const int A = v->A, L = v->L, E = v->E;
-    if (v->h->c.scenario == GMPE_SCENARIO_ROT_INV) { node_features_rot(v, i, node); goto mask; }
+    if (is_rotfam(&v->h->c)) { node_features_rot(v, i, node); goto mask; }
     {
     double evx, evy; agent_vel(v, i, &evx, &evy);
     const double px = v->x[i], py = v->y[i];
@@ -747,7 +797,8 @@ static void reset_world_july(envv* v) {
     const double a = 3 * size * 2.5, b = ws * 0.15;
     const double width = a > b ? a : b;                               /* 525-528 */
     const double angle = uniform(h, n, -M_PI / 2, M_PI / 2);          /* 530 */
-    const double tl = ws * 0.8;
+    double tl = ws * 0.8;
+    if (is_phasefam(c)) tl += uniform(h, n, -ws * 0.3, ws * 0.1);      /* two_phase_graph.py:506 */
     const double ca = cos(angle), sa = sin(angle);
     const double be = tl / 4, bx = -tl / 4;
     const double entx = ca * 0 + sa * be, enty = -sa * 0 + ca * be;   /* R @ [0, +len/4] (545-553) */
@@ -762,7 +813,7 @@ static void reset_world_july(envv* v) {
     int k = 0, tries = 0;
     while (k < v->A) {                                                /* random_scenario 452-486 */
         const double u0 = draw(h, n), u1 = draw(h, n);
-        const int rot = c->scenario == GMPE_SCENARIO_ROT_INV;                /* rot_inv.py:463, 469: 0.3 and /3 */
+        const int rot = is_rotfam(c);                                        /* rot_inv.py:463, 469: 0.3 and /3 */
         const double jf = rot ? 0.3 : 0.2;
         const double jx = jf * (-ws + (ws - (-ws)) * u0), jy = jf * (-ws + (ws - (-ws)) * u1);
         const double dfe = rot ? (ws + k) / 3 : (ws + k) / 5;
@@ -824,7 +875,7 @@ static void env_reset(envv* v, double* obs, int32_t* ids, double* node, double* 
     if (is_tube(&h->c)) reset_world_july(v); else reset_world_nav(v);
     calculate_distances(v);                     /* initialize_min_time_distance_graph (735-739) */
     double otmp[32], ntmp[GMPE_MAX_ENTITIES * 8];
-    const int F = h->F, rotinv = h->c.scenario == GMPE_SCENARIO_ROT_INV;
+    const int F = h->F, rotinv = is_rotfam(&h->c);
     for (int i = 0; i < A; ++i) {
         if (rotinv) observation_rot(v, i, otmp); else observation(v, i, otmp);
         graph_observation(v, i, ntmp);
@@ -907,8 +958,8 @@ static int env_step(envv* v, const int32_t* act, double* obs, int32_t* ids, doub
     double otmp[32], ntmp[GMPE_MAX_ENTITIES * 8], itmp[GMPE_INFO_KEYS], rsum = 0;
     int all_done = 1;
     for (int i = 0; i < A; ++i) {                /* environment.py:1036-1053, IN ORDER */
-        if (c->scenario == GMPE_SCENARIO_ROT_INV) observation_rot(v, i, otmp); else observation(v, i, otmp);
-        const double r = c->scenario == GMPE_SCENARIO_TUBE_JULY ? reward_july(v, i) : (c->scenario == GMPE_SCENARIO_ROT_INV ? reward_rot(v, i) : reward_nav(v, i));
+        if (is_rotfam(c)) observation_rot(v, i, otmp); else observation(v, i, otmp);
+        const double r = c->scenario == GMPE_SCENARIO_TUBE_JULY ? reward_july(v, i) : (is_rotfam(c) ? reward_rot(v, i) : reward_nav(v, i));
         graph_observation(v, i, ntmp);
         const int dn = v->status[i] || h->current_step[n] >= c->episode_length;   /* _get_done 264-271 */
         info_callback(v, i, r, itmp);

@@ -84,7 +84,7 @@ def july_rollout(num_agents, seed, T, world_size=4.0, episode_length=25, guided=
                  scenario_name="nav_metered_one_goal_graph_rotate_tube_july"):
     np.random.seed(seed)
     args = H.july_args(num_agents, world_size=world_size, episode_length=episode_length, scenario_name=scenario_name)
-    info_keys = INFO_KEYS + (["Phase_reached"] if "rot_inv" in scenario_name else [])
+    info_keys = INFO_KEYS + (["Phase_reached"] if ("rot_inv" in scenario_name or "phase_graph" in scenario_name) else [])
     with H.UniformTape() as tape:
         env, sc, w = H.make_july_env(args)
         A = num_agents
@@ -326,8 +326,7 @@ def misc_fixture():
                              DC.COMMUNICATION_RANGE]))
 
 
-def main():
-    H.selfcheck_uniform_patch()
+def main_july():
     jobs = [(3, 0, 60, 4.0, 25, False), (3, 1, 60, 4.0, 25, False), (10, 0, 55, 4.0, 25, False),
             (3, 2, 130, 2.0, 60, True), (3, 3, 130, 2.0, 60, True), (6, 4, 130, 3.0, 70, True),
             (10, 5, 100, 4.0, 90, True)]
@@ -338,10 +337,12 @@ def main():
         print(p, os.path.getsize(p), "resets", int(d["did_reset"].sum()),
               "steps with a done agent", int(d["st_status"].any(axis=1).sum()),
               "max phase", int(d["obs"][:, :, 18].max()), "phase_reached", d["st_phase_reached"].max(axis=0))
+
+
+def main_rot(ROT="nav_graph_metered_single_corridor_rot_inv", prefix="rotinv", seed=5, phase_col=12):
     # rot_inv. The reference crashes at env construction for some seeds (an agent placed inside the
     # tube before `previous_phase` exists: AttributeError in get_agent_phase, rot_inv.py:712) — such seeds are skipped.
-    ROT = "nav_graph_metered_single_corridor_rot_inv"
-    seed = 5
+    # The two/three-phase variants (same family, D = 15) reuse this generator with their own prefix.
     for A, T, ws, el, guided in [(3, 60, 4.0, 25, False), (10, 40, 4.0, 25, False), (3, 130, 2.0, 60, True),
                                  (3, 130, 2.0, 60, True), (6, 130, 3.0, 70, True), (10, 100, 4.0, 90, True)]:
         while True:
@@ -351,16 +352,34 @@ def main():
                 break
             except AttributeError as e:
                 print("seed", seed, "reference crashed:", str(e)[:70])
-        p = os.path.join(HERE, "rotinv_A%d_s%d%s.npz" % (A, seed, "_guided" if guided else ""))
+        p = os.path.join(HERE, "%s_A%d_s%d%s.npz" % (prefix, A, seed, "_guided" if guided else ""))
         np.savez_compressed(p, **d)
         print(p, os.path.getsize(p), "resets", int(d["did_reset"].sum()), "steps with a done agent", int(d["st_status"].any(axis=1).sum()),
-              "max phase", int(d["obs"][:, :, 12].max()), "phase_reached", d["st_phase_reached"].max(axis=0), "cooldown max", d["st_cooldown"].max())
+              "max phase", int(d["obs"][:, :, phase_col].max()), "phase_reached", d["st_phase_reached"].max(axis=0), "cooldown max", d["st_cooldown"].max())
+
+
+def main_blocks():
     np.savez_compressed(os.path.join(HERE, "rk45_airtaxi.npz"), **rk45_fixture())
     np.savez_compressed(os.path.join(HERE, "force_classic.npz"), **force_classic_fixture())
     np.savez_compressed(os.path.join(HERE, "force_di.npz"), **force_di_fixture())
     np.savez_compressed(os.path.join(HERE, "misc.npz"), **misc_fixture())
+
+
+def main(which):
+    """`python make_fixtures.py [july|rot|phase|blocks ...]` regenerates the named groups (default: all)."""
+    H.selfcheck_uniform_patch()
+    which = which or ["july", "rot", "phase", "blocks"]
+    if "july" in which:
+        main_july()
+    if "rot" in which:
+        main_rot()
+    if "phase" in which:
+        main_rot("two_phase_graph", "twophase", seed=20, phase_col=14)
+        main_rot("three_phase_graph", "threephase", seed=40, phase_col=14)
+    if "blocks" in which:
+        main_blocks()
     print("done")
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:])
