@@ -106,8 +106,9 @@ __device__ __forceinline__ bool in_tube_rect(double s, double y, double L, doubl
 __device__ __forceinline__ bool in_entrance_gate(double s, double y, double L, double hw) {
     return (-(0.02 * L) - 0.05 <= s && s <= 0.08 * L + 0.05) && (fabs(y) <= hw + 0.05);
 }
-__device__ __forceinline__ bool in_exit_gate(double s, double y, double L, double hw) {
-    return (L - 0.05 * L - 0.05 <= s && s <= L + 0.08 * L + 0.05) && (fabs(y) <= hw + 0.05);
+// exit_back_ratio: 0.05 in rot_inv (:619), 0.02 in two_phase_graph.py:589 / three_phase_graph.py
+__device__ __forceinline__ bool in_exit_gate(double s, double y, double L, double hw, double back_ratio) {
+    return (L - back_ratio * L - 0.05 <= s && s <= L + 0.08 * L + 0.05) && (fabs(y) <= hw + 0.05);
 }
 __device__ __forceinline__ double entrance_gate_distance(double s, double y, double hw) { return hypot(fabs(s), y - clipd(y, -hw, hw)); }
 __device__ __forceinline__ double exit_gate_distance(double s, double y, double L, double hw) {
@@ -115,17 +116,33 @@ __device__ __forceinline__ double exit_gate_distance(double s, double y, double 
     return hypot(ds, y - clipd(y, -hw, hw));
 }
 // pure function of (pos, previous_phase, phase_reached); the caller decrements the cooldown (:700-702)
+// VARIANT 0: rot_inv; 1: two_phase_graph.py:660-701 (exit gate reached from inside the tube); 2: three_phase_graph.py:656-699
+template <int VARIANT>
 __device__ __forceinline__ int phase_eval_rot(const double* tube, double px, double py, int prev, int phase_reached) {
     const double L = tube[T_L], hw = tube[T_HALFW];
     double s, yy; tube_sy(tube, px, py, s, yy);
     const bool in_tube = in_tube_rect(s, yy, L, hw), passed = s > L;
+    const bool valid_exit = in_exit_gate(s, yy, L, hw, VARIANT ? 0.02 : 0.05);
     if (!in_tube && !passed) return 0;
-    if (in_tube) return prev == 0 ? (in_entrance_gate(s, yy, L, hw) ? 1 : 0) : 1;
+    if (in_tube) {
+        if (prev == 0) return in_entrance_gate(s, yy, L, hw) ? 1 : 0;
+        if (VARIANT >= 1 && prev == 1 && valid_exit) return 2;
+        if (VARIANT == 2 && prev == 2 && valid_exit) return 2;
+        return 1;
+    }
     if (phase_reached >= 1) {
-        if (prev == 1 && in_exit_gate(s, yy, L, hw)) return 2;
+        if (prev == 1 && valid_exit) return 2;
         if (prev == 2) return 2;
     }
     return 0;
+}
+// (theta - arctan2(e_y, e_x) + pi) % 2pi - pi with NumPy's float modulo (sign of the divisor) — two_phase_graph.py:1060-1063
+__device__ __forceinline__ double heading_error_signed(const double* tube, double th) {
+    const double ch = atan2(tube[T_EY], tube[T_EX]);
+    const double a = th - ch + M_PI, b = 2 * M_PI;
+    double m = fmod(a, b);
+    if (m != 0.0) { if (m < 0) m += b; } else m = 0.0;
+    return m - M_PI;
 }
 // get_rotated_position_from_relative (:91-97): [[c, s], [-s, c]] @ v
 __device__ __forceinline__ void rot2(double c, double s, double vx, double vy, double& ox, double& oy) { ox = c * vx + s * vy; oy = -s * vx + c * vy; }

@@ -18,8 +18,10 @@ enum { MODE_STEP = 0, MODE_RESET = 1 };
 // Scenario variant = compile-time parameter of the kernel: each variant's observation / reward / reset code is compiled
 // into its own instantiation (gmpe_sc.hip, one translation unit per variant), so adding a scenario never costs the
 // others registers. navigation_graph has a wall-less variant: the wall contact code is the largest register consumer.
-enum { SC_NAV = 0, SC_NAV_WALLS = 1, SC_JULY = 2, SC_ROT = 3, SC_COUNT = 4 };
+enum { SC_NAV = 0, SC_NAV_WALLS = 1, SC_JULY = 2, SC_ROT = 3, SC_TWO = 4, SC_THREE = 5, SC_COUNT = 6 };
 __host__ __device__ constexpr bool sc_kinematic(int sc) { return sc >= SC_JULY; }
+__host__ __device__ constexpr bool sc_rotfam(int sc) { return sc >= SC_ROT; }                     // rotated-frame float32 features, F = 7
+__host__ __device__ constexpr bool sc_phasefam(int sc) { return sc == SC_TWO || sc == SC_THREE; }  // D = 15, random tube length
 
 struct KParams {
     gmpe_config c;
@@ -208,10 +210,13 @@ __device__ __forceinline__ void write_obs(const KParams& p, const Lds& l, int i,
     }
 }
 
-// Scenario.observation of rot_inv (…rot_inv.py:1453-1548): 13 float32 = [cos th, sin th, speed, goal (rotated), two nearest
-// neighbours (rel. vector cast to float32, then rotated in float64), s/L, y/half_w (clipped), exit-gate distance / L, phase].
-// Uses the PRE-reward heading (the reward of this agent runs after its observation).
-template <int AP>
+// Scenario.observation of the rot_inv family (…rot_inv.py:1453-1548): float32 = [cos th, sin th, speed, goal (rotated), two
+// nearest neighbours (rel. vector cast to float32, then rotated in float64), s/L, y/half_w (clipped), exit-gate distance / L,
+// phase] = 13; two_phase_graph.py:1152-1236 / three_phase_graph.py put [cos, sin](heading error to the corridor axis) before the
+// phase (D = 15), skip finished agents among the neighbours, and two_phase replaces the goal vector by float32(exit) - pos.
+// Uses the PRE-reward heading (the reward of this agent runs after its observation); agent k counts as finished for ego i
+// iff s_old[k] or (new[k] and k < i) — the ordered-visibility rule.
+template <int AP, int SC>
 __device__ __forceinline__ void write_obs_rot(const KParams& p, const Lds& l, int i, int phase) {
     float* o = l.obs + (size_t)i * p.D;
     const double px = l.ex[i], py = l.ey[i], th = l.s2[i];
@@ -220,12 +225,16 @@ __device__ __forceinline__ void write_obs_rot(const KParams& p, const Lds& l, in
     int b1 = -1, b2 = -1; double d1 = INF, d2 = INF;
     const double* row = l.Dm + (size_t)i * p.E;
     for (int k = 0; k < p.A; ++k) {
-        const double d = k != i ? row[k] : INF;
+        bool skip = k == i;
+        if (sc_phasefam(SC)) skip = skip || l.s_old[k] || (l.newf[k] && k < i);
+        const double d = !skip ? row[k] : INF;
         const bool lt1 = d < d1, lt2 = d < d2;
         d2 = lt1 ? d1 : (lt2 ? d : d2); b2 = lt1 ? b1 : (lt2 ? k : b2);
         d1 = lt1 ? d : d1; b1 = lt1 ? k : b1;
     }
-    double gx, gy; rot2(cs, sn, l.ex[p.A + i] - px, l.ey[p.A + i] - py, gx, gy);
+    double gx, gy;
+    if (SC == SC_TWO) rot2(cs, sn, (double)(float)l.tube[T_EXX] - px, (double)(float)l.tube[T_EXY] - py, gx, gy);
+    else rot2(cs, sn, l.ex[p.A + i] - px, l.ey[p.A + i] - py, gx, gy);
     double n1x = 0, n1y = 0, n2x = 0, n2y = 0;
     if (b1 >= 0) rot2(cs, sn, (double)(float)(l.ex[b1] - px), (double)(float)(l.ey[b1] - py), n1x, n1y);
     if (b2 >= 0) rot2(cs, sn, (double)(float)(l.ex[b2] - px), (double)(float)(l.ey[b2] - py), n2x, n2y);
@@ -234,7 +243,11 @@ __device__ __forceinline__ void write_obs_rot(const KParams& p, const Lds& l, in
     o[0] = (float)cs; o[1] = (float)sn; o[2] = (float)l.s3[i];
     o[3] = (float)gx; o[4] = (float)gy; o[5] = (float)n1x; o[6] = (float)n1y; o[7] = (float)n2x; o[8] = (float)n2y;
     o[9] = (float)clipd(s / L, -2.0, 2.0); o[10] = (float)clipd(yy / (hw + 1e-9), -2.0, 2.0);
-    o[11] = (float)(exit_gate_distance(s, yy, L, hw) / (L + 1e-9)); o[12] = (float)phase;
+    o[11] = (float)(exit_gate_distance(s, yy, L, hw) / (L + 1e-9));
+    if (sc_phasefam(SC)) {
+        double hs, hc; sincos(heading_error_signed(l.tube, th), &hs, &hc);
+        o[12] = (float)hc; o[13] = (float)hs; o[14] = (float)phase;
+    } else o[12] = (float)phase;
 }
 
 // Serial reset of one env by ONE lane (reset_world: …_july.py:339-420, 440-515, 518-613,
@@ -250,7 +263,8 @@ __device__ __forceinline__ void reset_world_serial(const KParams& p, const Lds& 
         const double a = 3 * size * 2.5, b = ws * 0.15;
         const double width = a > b ? a : b;
         const double angle = -M_PI / 2 + (M_PI / 2 - (-M_PI / 2)) * draw_at(c, p.s, n, ctr++, err);
-        const double tl = ws * 0.8;
+        double tl = ws * 0.8;
+        if (sc_phasefam(SC)) tl += -ws * 0.3 + (ws * 0.1 - (-ws * 0.3)) * draw_at(c, p.s, n, ctr++, err);   // two_phase_graph.py:506
         const double ca = cos(angle), sa = sin(angle);
         const double be = tl / 4, bx = -tl / 4;
         const double entx = ca * 0 + sa * be, enty = -sa * 0 + ca * be;
@@ -266,7 +280,7 @@ __device__ __forceinline__ void reset_world_serial(const KParams& p, const Lds& 
         int k = 0, tries = 0;
         while (k < A) {
             const double u0 = draw_at(c, p.s, n, ctr++, err), u1 = draw_at(c, p.s, n, ctr++, err);
-            constexpr bool rot = SC == SC_ROT;              // rot_inv.py:463, 469
+            constexpr bool rot = sc_rotfam(SC);             // rot_inv.py:463, 469
             const double jf = rot ? 0.3 : 0.2;
             const double jx = jf * (-ws + (ws - (-ws)) * u0), jy = jf * (-ws + (ws - (-ws)) * u1);
             const double dfe = rot ? (ws + k) / 3 : (ws + k) / 5;
@@ -438,7 +452,7 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, 
         }
     }
     
-    if (SC == SC_ROT && p.o.node_obs && !(abl & 2)) {
+    if (sc_rotfam(SC) && p.o.node_obs && !(abl & 2)) {
         // rot_inv node row (…rot_inv.py:1690-1766): 7 float32 = [rel_vel, rel_pos, rel_goal (all rotated by the ego heading), type].
         // Positions / velocities are rounded to float32 FIRST, differenced in float32, rotated in float64, rounded again.
         // A lane owns one (env, entity) and walks the egos; rows are 28 B, so the stores are scalar.
@@ -453,7 +467,9 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, 
             const float kvox = kag ? (float)l.vox[ab + kk] : 0.0f, kvoy = kag ? (float)l.voy[ab + kk] : 0.0f;
             const float kvnx = kag ? (float)l.vnx[ab + kk] : 0.0f, kvny = kag ? (float)l.vny[ab + kk] : 0.0f;
             const bool knew = kag && l.newf[ab + kk] != 0;
-            const float gxk = kag ? (float)l.ex[eb + A + kk] : 0.0f, gyk = kag ? (float)l.ey[eb + A + kk] : 0.0f;
+            // goal node feature of an agent: its landmark; in two_phase_graph.py:1405 the corridor exit
+            const float gxk = SC == SC_TWO ? (float)l.tube[gg * GMPE_TUBE_STRIDE + T_EXX] : (kag ? (float)l.ex[eb + A + kk] : 0.0f);
+            const float gyk = SC == SC_TWO ? (float)l.tube[gg * GMPE_TUBE_STRIDE + T_EXY] : (kag ? (float)l.ey[eb + A + kk] : 0.0f);
             const float typ = kag ? 0.0f : (k < A + L ? 1.0f : 2.0f);
             for (int ei = 0; ei < A; ++ei) {
                 const float apx = (float)l.ex[eb + ei], apy = (float)l.ey[eb + ei];
@@ -473,7 +489,7 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, 
             }
         }
     }
-    if (SC != SC_ROT && p.o.node_obs && !(abl & 2)) {
+    if (!sc_rotfam(SC) && p.o.node_obs && !(abl & 2)) {
         // node row (ego, entity k) = 2 float4: [rel_vel, rel_pos] and [rel_goal, occupied, type].
         // A lane owns one (env, entity, half) slot, keeps that entity's data in registers and walks the egos.
         float4* base = reinterpret_cast<float4*>(p.o.node_obs + (size_t)n0 * A * E * GMPE_NODE_FEATS);
@@ -540,7 +556,8 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
     const Lds l = carve(smem, G, A, E, D);
     const int n0 = blockIdx.x * G;
     const int Gv = min(G, N - n0);                                      // envs actually present in this tile
-    constexpr bool july = SC == SC_JULY, rotinv = SC == SC_ROT;
+    constexpr bool july = SC == SC_JULY, rotinv = SC == SC_ROT, rotfam = sc_rotfam(SC), two = SC == SC_TWO, three = SC == SC_THREE;
+    constexpr int PV = two ? 1 : (three ? 2 : 0);                        // phase FSM variant (gmpe_device.h)
     const bool step = p.mode == MODE_STEP;
     constexpr bool kin = sc_kinematic(SC);
     const int EE = E * E, EE4 = (EE + 3) / 4 * 4, AD4 = (A * D + 3) / 4 * 4;
@@ -737,17 +754,19 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
                 if (cooldown > 0) cooldown -= 1;
                 prevA = prevB;
                 goal_branch = (cp == 2 && phase_reached != 0);
-            } else if (rotinv) {
+            } else if (rotfam) {
                 // rot_inv.py:675-739: the query mutates only the cooldown, so observation's and reward's calls agree;
-                // phase 2 is only returned with phase_reached >= 1, hence the goal block runs iff cp == 2 (:1281-1297)
-                ph1 = phase_eval_rot(v.tube, px, py, prev_phase, phase_reached);
+                // phase 2 is only returned with phase_reached >= 1, hence the goal block runs iff cp == 2 (:1281-1297).
+                // three_phase has no demotion either (:1110); in two_phase the agent finishes at the 1 -> 2 transition.
+                ph1 = phase_eval_rot<PV>(v.tube, px, py, prev_phase, phase_reached);
                 if (cooldown > 0) cooldown -= 1;
                 if (cooldown > 0) cooldown -= 1;
                 cp = ph1;
-                goal_branch = (cp == 2);
+                goal_branch = (cp == 2) && (rotinv ? phase_reached >= 1 : true);
             }
             dgoal = v.Dm[(size_t)i * E + A + i];
-            v.newf[i] = goal_branch && dgoal < c.goal_thresh && !v.s_old[i];
+            if (two) v.newf[i] = cp == 2 && prev_phase == 1 && phase_reached == 1 && !v.s_old[i];   // two_phase_graph.py:1023-1044
+            else v.newf[i] = goal_branch && dgoal < c.goal_thresh && !v.s_old[i];
         }
         // rank of each newly-reached agent among its env's: heading re-draws follow agent order (core.py:328)
         if (tid < 64) {
@@ -757,11 +776,11 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
                     const int rank = __popcll(bal & emask & ((1ull << tid) - 1ull));
                     if (kin) { v.n2[i] = 0.0 + (2 * M_PI - 0.0) * draw_at(c, p.s, n, ctr0 + rank, err); v.n3[i] = c.v_min; }
                     else { v.n2[i] = 0.0; v.n3[i] = 0.0; }
-                    v.gt[i] = i;
+                    if (!two && !three) v.gt[i] = i;                          // the phase-graph files never write goal_tracker (three_phase_graph.py:1119)
                     double vx, vy; vel_of<SC>(v.n2[i], v.n3[i], vx, vy);
                     v.vnx[i] = vx; v.vny[i] = vy;
                 } else { v.n2[i] = v.s2[i]; v.n3[i] = v.s3[i]; v.vnx[i] = v.vox[i]; v.vny[i] = v.voy[i]; }
-                if (rotinv) { double sn_, cn_; sincos(v.n2[i], &sn_, &cn_); v.cn[i] = cn_; v.sn[i] = sn_; }
+                if (rotfam) { double sn_, cn_; sincos(v.n2[i], &sn_, &cn_); v.cn[i] = cn_; v.sn[i] = sn_; }
                 if (i == 0) v.flags[1] = kin ? __popcll(bal & emask) : 0;   // draws consumed (DI reset_velocity draws none)
                 // done flag (_get_done environment.py:264-271) and this step's adjacency mask (…_july.py:1627-1648:
                 // done agents, reached landmarks) depend only on status / goal_tracker: known before the rewards
@@ -814,7 +833,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
             if (ag) {
                 const double px = v.ex[i], py = v.ey[i];
                 const double* row = v.Dm + (size_t)i * E;
-                if (rotinv) write_obs_rot<AP>(p, v, i, ph1); else write_obs<AP, SC>(p, v, i, v.vox[i], v.voy[i], ph1);
+                if (rotfam) write_obs_rot<AP, SC>(p, v, i, ph1); else write_obs<AP, SC>(p, v, i, v.vox[i], v.voy[i], ph1);
                 STAMP(13);
                 // collision block (…_july.py:1117-1124) and info_callback's collision count (:780-786) in one sweep
                 int ncol_r = 0, ncol_i = 0;
@@ -840,11 +859,14 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
                 }
                 if (me_old) { ncol_r = 0; }
                 if (me_old || me_new) ncol_i = 0;
-                for (int q = 0; q < ncol_r; ++q) rew -= c.collision_rew * 4;
+                // reward term per contact: 4 x collision_rew (…_july.py:1117-1124, rot_inv.py:1134-1139); three_phase_graph.py:965-970: 1 x;
+                // two_phase_graph.py: none (block commented out)
+                if (three) { for (int q = 0; q < ncol_r; ++q) rew -= c.collision_rew; }
+                else if (!two) for (int q = 0; q < ncol_r; ++q) rew -= c.collision_rew * 4;
                 nac += ncol_i;
                 STAMP(14);
                 const bool obst_hit = obstacle_collision_ego(p, v, i);
-                if (obst_hit) { rew -= c.collision_rew * 3; noc += 1; }
+                if (obst_hit) { if (!two && !three) rew -= c.collision_rew * 3; noc += 1; }
                 double serr = 0;
                 if (july) {
                     const double tdx = v.tube[T_EXX] - v.tube[T_ENTX], tdy = v.tube[T_EXY] - v.tube[T_ENTY];
@@ -885,23 +907,29 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
                     if (cp < prevA) rew -= c.collision_rew * 3;
                     if (cp < phase_reached) rew -= c.collision_rew;
                     prev_phase = cp;
-                } else if (rotinv) {
-                    // Scenario.reward, rot_inv.py:1122-1338
+                } else if (rotfam) {
+                    // Scenario.reward, rot_inv.py:1122-1338; two_phase_graph.py:955-1142; three_phase_graph.py:957-1160
                     const double Lt = v.tube[T_L], hw = v.tube[T_HALFW];
                     double ts, ty; tube_sy(v.tube, px, py, ts, ty);
                     if (cp == 2 && cp > prev_phase + 1) rew -= c.goal_rew;
                     if (cp == prev_phase + 1 && phase_reached == cp - 1) {
                         if (cp == 1 && in_entrance_gate(ts, ty, Lt, hw) && cooldown == 0) {
                             rew += c.goal_rew;
-                            cooldown = (int)((double)c.episode_length / 10);       // float into an int32 array (:1200, :228)
+                            // rot_inv: episode_length/10 as a float into an int32 array (:1200, :228); phase graphs: episode_length
+                            cooldown = (two || three) ? c.episode_length : (int)((double)c.episode_length / 10);
                             phase_reached = 1;
-                        } else if (cp == 2) { rew += c.goal_rew; phase_reached = 2; }
+                        } else if (cp == 2) {
+                            rew += c.goal_rew; phase_reached = 2;
+                            if (two && me_new) rew += c.goal_rew * 5;                               // finished at the exit gate (:1040-1044)
+                        }
                     }
-                    if (cp == 0) rew -= entrance_gate_distance(ts, ty, hw);
-                    else if (cp == 1) {
-                        const double tdx = v.tube[T_EXX] - v.tube[T_ENTX], tdy = v.tube[T_EXY] - v.tube[T_ENTY];
-                        const double tlen = sqrt(tdx * tdx + tdy * tdy);
-                        const double proj = (px - v.tube[T_ENTX]) * (tdx / tlen) + (py - v.tube[T_ENTY]) * (tdy / tlen);
+                    double herr = 0;
+                    if (two || three) herr = fabs(heading_error_signed(v.tube, v.s2[i]));           // pre-reward heading
+                    if (cp == 0) {
+                        const double de = entrance_gate_distance(ts, ty, hw);
+                        rew -= de;
+                        if ((two || three) && de < c.world_size * 0.1) rew -= herr * c.formation_rew * 0.5;
+                    } else if (cp == 1) {
                         double hx, hy; sincos(v.s2[i], &hy, &hx);
                         int front = -1, back = -1; double fproj = 0, bproj = 0;
                         for (int k = 0; k < A; ++k) {
@@ -915,13 +943,18 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
                         if (serr > 0) sv += 1;
                         rew -= serr * c.formation_rew;
                         rew -= exit_gate_distance(ts, ty, Lt, hw);
-                        const double gain = c.goal_rew / (c.world_size * 0.8 * 10);             // :522
-                        const double dproj = proj - pproj;
-                        rew += gain * (dproj > -0.05 ? dproj : -0.05);
+                        if (rotinv) {
+                            const double tdx = v.tube[T_EXX] - v.tube[T_ENTX], tdy = v.tube[T_EXY] - v.tube[T_ENTY];
+                            const double tlen = sqrt(tdx * tdx + tdy * tdy);
+                            const double proj = (px - v.tube[T_ENTX]) * (tdx / tlen) + (py - v.tube[T_ENTY]) * (tdy / tlen);
+                            const double gain = c.goal_rew / (c.world_size * 0.8 * 10);         // :522
+                            const double dproj = proj - pproj;
+                            rew += gain * (dproj > -0.05 ? dproj : -0.05);
+                            pproj = (double)(float)proj;                                       // float32 array (:374)
+                        } else rew -= herr * c.formation_rew * 0.1;
                         sic += 1;
-                        pproj = (double)(float)proj;                                           // float32 array (:374)
-                    } else if (cp == 2 && phase_reached == 0) cp = 0;
-                    else if (cp == 2) {
+                    } else if (rotinv && cp == 2 && phase_reached == 0) cp = 0;
+                    else if (cp == 2 && !two) {
                         if (dgoal < c.goal_thresh) { if (me_new) rew += c.goal_rew * 5; }
                         else rew -= dgoal;
                     }
@@ -930,15 +963,15 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
                     if (cp < prev_phase) rew -= c.collision_rew;
                     if (cp < phase_reached) rew -= c.collision_rew;
                     prev_phase = cp;
-                    if (in_tube_rect(ts, ty, Lt, hw) && cp != 1) rew -= c.collision_rew;
+                    if (in_tube_rect(ts, ty, Lt, hw) && cp != 1 && !(three && in_exit_gate(ts, ty, Lt, hw, 0.02))) rew -= c.collision_rew;
                     if (ts > Lt && phase_reached < 1) rew -= c.goal_rew;
                 } else {
                     if (dgoal < c.goal_thresh) { if (me_new) rew += c.goal_rew * 5; }
                     else rew -= dgoal;
                 }
                 rew = clipd(rew, -4 * c.collision_rew, c.goal_rew * 5);
-                if (!rotinv) rew = clipd(rew, c.min_reward, c.max_reward);                      // rot_inv.py:1338 clips once
-                v.serr[i] = serr; v.rew[i] = rew;
+                if (!rotfam) rew = clipd(rew, c.min_reward, c.max_reward);                      // rot_inv.py:1338 clips once
+                v.serr[i] = two ? 0.0 : serr; v.rew[i] = rew;           // two_phase_graph.py never appends to delta_spacing
 
                 STAMP(15);
                 // ---- info counters that depend on own data only (…_july.py:744-773)
@@ -982,7 +1015,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
                         ssv += ok ? (nw ? svn : svo) : 0;
                     }
                     double dsp = dsp0;
-                    if (july || rotinv) for (int a = 0; a <= i; ++a) dsp += v.serr[a];   // same order as the list append (:1180)
+                    if (july || rotfam) for (int a = 0; a <= i; ++a) dsp += v.serr[a];   // same order as the list append (:1180)
                     const double dm = sd / A, tm = st / A;
                     // population variance = (A*sum(x^2) - sum(x)^2) / A^2, numerator exact
                     const double dvn = (double)A * sdd - sd * sd, tvn = (double)A * stt - st * st;
@@ -1000,7 +1033,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
                 if (!all_done) {                                            // persist the stepped state
                     if (i == 0) {
                         double dsp = dsp0;
-                        if (july || rotinv) for (int a = 0; a < A; ++a) dsp += v.serr[a];
+                        if (july || rotfam) for (int a = 0; a < A; ++a) dsp += v.serr[a];
                         p.s.delta_spacing[n] = dsp;
                         p.s.rng_ctr[n] = ctr0 + v.flags[1];
                         p.s.current_step[n] = cur_step;
@@ -1052,7 +1085,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
                 int prevA = prev_phase, ph = 0;
                 if (july) ph = phase_eval(v.tube, v.ex[i], v.ey[i], prev_phase, prevA);   // reset-time observation (:1447)
                 prev_phase = prevA;
-                if (rotinv) { ph = phase_eval_rot(v.tube, v.ex[i], v.ey[i], prev_phase, 0); double sn_, cn_; sincos(v.n2[i], &sn_, &cn_); v.cn[i] = cn_; v.sn[i] = sn_; p.s.prev_proj[na] = 0.0; }
+                if (rotfam) { ph = phase_eval_rot<PV>(v.tube, v.ex[i], v.ey[i], prev_phase, 0); double sn_, cn_; sincos(v.n2[i], &sn_, &cn_); v.cn[i] = cn_; v.sn[i] = sn_; p.s.prev_proj[na] = 0.0; }
                 const double dx = v.ex[i] - v.ex[A + i], dy = v.ey[i] - v.ey[A + i];
                 gmt = c.max_speed > 0 ? sqrt(dx * dx + dy * dy) / c.max_speed : 0.0;
                 p.s.x[na] = v.ex[i]; p.s.y[na] = v.ey[i]; p.s.s2[na] = v.n2[i]; p.s.s3[na] = v.n3[i];
@@ -1068,7 +1101,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
             distance_pass<BLOCK>(p, l, Gv, tid, true);
             static_block<BLOCK>(p, l, Gv, tid, true);
             __syncthreads();
-            if (mine) { if (rotinv) write_obs_rot<AP>(p, v, i, ph1); else write_obs<AP, SC>(p, v, i, v.vox[i], v.voy[i], ph1); }
+            if (mine) { if (rotfam) write_obs_rot<AP, SC>(p, v, i, ph1); else write_obs<AP, SC>(p, v, i, v.vox[i], v.voy[i], ph1); }
             any_mask = 0;
             for (int gg = 0; gg < Gv; ++gg) any_mask |= l.flags[gg * 4 + 2];
         }

@@ -128,6 +128,8 @@ static int sc_of(const gmpe_config& c) {
     switch (c.scenario) {
         case GMPE_SCENARIO_TUBE_JULY: return SC_JULY;
         case GMPE_SCENARIO_ROT_INV: return SC_ROT;
+        case GMPE_SCENARIO_TWO_PHASE: return SC_TWO;
+        case GMPE_SCENARIO_THREE_PHASE: return SC_THREE;
         default: return c.num_walls > 0 ? SC_NAV_WALLS : SC_NAV;
     }
 }
@@ -136,7 +138,9 @@ static hipError_t sc_dispatch_lds(int sc, int lds) {
         case SC_NAV: return set_max_lds<SC_NAV>(lds);
         case SC_NAV_WALLS: return set_max_lds<SC_NAV_WALLS>(lds);
         case SC_JULY: return set_max_lds<SC_JULY>(lds);
-        default: return set_max_lds<SC_ROT>(lds);
+        case SC_ROT: return set_max_lds<SC_ROT>(lds);
+        case SC_TWO: return set_max_lds<SC_TWO>(lds);
+        default: return set_max_lds<SC_THREE>(lds);
     }
 }
 
@@ -144,8 +148,14 @@ extern "C" {
 
 int gmpe_abi_version(void) { return GMPE_ABI_VERSION; }
 const char* gmpe_last_error(void) { return g_err.c_str(); }
-int gmpe_obs_dim(const gmpe_config* c) { return c->scenario == GMPE_SCENARIO_TUBE_JULY ? 19 : 13; }
-int gmpe_node_feats(const gmpe_config* c) { return c->scenario == GMPE_SCENARIO_ROT_INV ? 7 : GMPE_NODE_FEATS; }
+int gmpe_obs_dim(const gmpe_config* c) {
+    switch (c->scenario) {
+        case GMPE_SCENARIO_TUBE_JULY: return 19;
+        case GMPE_SCENARIO_TWO_PHASE: case GMPE_SCENARIO_THREE_PHASE: return 15;
+        default: return 13;
+    }
+}
+int gmpe_node_feats(const gmpe_config* c) { return c->scenario >= GMPE_SCENARIO_ROT_INV ? 7 : GMPE_NODE_FEATS; }
 int gmpe_num_entities(const gmpe_config* c) { return c->num_agents + c->num_landmarks + c->num_obstacles; }
 
 static int field_info(const gmpe_handle* h, int f, void** ptr, size_t* bytes) {
@@ -193,7 +203,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     if (cfg->num_envs < 1 || cfg->num_agents < 1 || cfg->num_agents > GMPE_MAX_AGENTS || cfg->num_landmarks < cfg->num_agents ||
         cfg->num_obstacles < 0 || cfg->num_walls < 0 || cfg->num_walls > GMPE_MAX_WALLS || E > GMPE_MAX_ENTITIES)
         return fail(GMPE_ERR_INVALID_ARG, "config out of range (agents<=64, entities<=160, walls<=8, landmarks>=agents)");
-    if (cfg->scenario != GMPE_SCENARIO_NAVIGATION_GRAPH && cfg->scenario != GMPE_SCENARIO_TUBE_JULY && cfg->scenario != GMPE_SCENARIO_ROT_INV)
+    if (cfg->scenario < GMPE_SCENARIO_NAVIGATION_GRAPH || cfg->scenario > GMPE_SCENARIO_THREE_PHASE)
         return fail(GMPE_ERR_UNSUPPORTED, "unknown scenario");
     if ((cfg->scenario != GMPE_SCENARIO_NAVIGATION_GRAPH) == (cfg->dynamics == GMPE_DYN_DOUBLE_INTEGRATOR))
         return fail(GMPE_ERR_UNSUPPORTED, "the tube scenarios are kinematic; navigation_graph is double_integrator");
@@ -374,7 +384,9 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
         case SC_NAV: launch_env<SC_NAV>(h->block, ap, grid, lds, st, p); break;
         case SC_NAV_WALLS: launch_env<SC_NAV_WALLS>(h->block, ap, grid, lds, st, p); break;
         case SC_JULY: launch_env<SC_JULY>(h->block, ap, grid, lds, st, p); break;
-        default: launch_env<SC_ROT>(h->block, ap, grid, lds, st, p); break;
+        case SC_ROT: launch_env<SC_ROT>(h->block, ap, grid, lds, st, p); break;
+        case SC_TWO: launch_env<SC_TWO>(h->block, ap, grid, lds, st, p); break;
+        default: launch_env<SC_THREE>(h->block, ap, grid, lds, st, p); break;
     }
     HIPCHK(hipGetLastError());
     if (h->timing) { HIPCHK(hipEventRecord(e1, st)); h->ev_used += 2; }

@@ -16,8 +16,9 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-JULY = sorted(glob.glob(os.path.join(GOLD, "july_A*_s*.npz"))) + sorted(glob.glob(os.path.join(GOLD, "rotinv_A*_s*.npz")))
+JULY = [q for pre in ("july", "rotinv", "twophase", "threephase") for q in sorted(glob.glob(os.path.join(GOLD, pre + "_A*_s*.npz")))]
 ROT = "nav_graph_metered_single_corridor_rot_inv"
+ROTFAM = [ROT, "two_phase_graph", "three_phase_graph"]
 TOL = 1e-5
 
 
@@ -51,8 +52,8 @@ def test_golden_replay_on_gpu(path):
     """The reference's own rollouts (incl. its np.random draws via the tape) replayed on the GPU."""
     d = np.load(path)
     A, E, T = int(d["A"]), int(d["E"]), int(d["T"])
-    rot = os.path.basename(path).startswith("rotinv")
-    eng = _engine(_july_cfg(d, ROT) if rot else _july_cfg(d))
+    rot = not os.path.basename(path).startswith("july")              # the rot_inv family: float32 rotated features, F = 7
+    eng = _engine(_july_cfg(d, str(d["scenario_name"])) if rot else _july_cfg(d))     # the July fixtures predate the name field
     assert _np(eng.out.node_obs).shape[-1] == (7 if rot else 8)
     eng.set("prev_phase", d["init_prev_phase"][None])
     eng.set_tape(d["tape"][None])
@@ -176,21 +177,24 @@ def test_july_tube_transit_vs_oracle():
     _rollout_vs_oracle(cfg, 45, seed=2, shrink_world=True)
 
 
-def test_rotinv_random_rollout_vs_oracle_philox():
-    cfg = gmpe.make_config(scenario_name=ROT, num_envs=96, num_agents=10, world_size=4.0, episode_length=12, seed=321)
-    assert cfg.node_feats == 7 and cfg.obs_dim == 13
+@pytest.mark.parametrize("scen", ROTFAM)
+def test_rotfam_random_rollout_vs_oracle_philox(scen):
+    cfg = gmpe.make_config(scenario_name=scen, num_envs=96, num_agents=10, world_size=4.0, episode_length=12, seed=321)
+    assert cfg.node_feats == 7 and cfg.obs_dim == (13 if scen == ROT else 15)
     assert _rollout_vs_oracle(cfg, 30, seed=5) >= 96 * 2
 
 
-def test_rotinv_tube_transit_vs_oracle():
-    """Agents pushed through the corridor: entrance-gate bonus + cooldown, progress reward, exit gate, goal reach."""
-    cfg = gmpe.make_config(scenario_name=ROT, num_envs=64, num_agents=4, world_size=2.4, episode_length=40, seed=9)
+@pytest.mark.parametrize("scen", ROTFAM)
+def test_rotfam_tube_transit_vs_oracle(scen):
+    """Agents pushed through the corridor: entrance-gate bonus + cooldown, progress / heading terms, exit gate, finish."""
+    cfg = gmpe.make_config(scenario_name=scen, num_envs=64, num_agents=4, world_size=2.4, episode_length=40, seed=9)
     _rollout_vs_oracle(cfg, 45, seed=6, shrink_world=True)
 
 
-def test_rotinv_three_agents_and_64_agents():
-    _rollout_vs_oracle(gmpe.make_config(scenario_name=ROT, num_envs=5, num_agents=3, world_size=4.0, episode_length=9, seed=2), 20, seed=7)
-    _rollout_vs_oracle(gmpe.make_config(scenario_name=ROT, num_envs=3, num_agents=64, world_size=30.0, episode_length=4, seed=3), 9, seed=8)
+@pytest.mark.parametrize("scen", ROTFAM)
+def test_rotfam_three_agents_and_64_agents(scen):
+    _rollout_vs_oracle(gmpe.make_config(scenario_name=scen, num_envs=5, num_agents=3, world_size=4.0, episode_length=9, seed=2), 20, seed=7)
+    _rollout_vs_oracle(gmpe.make_config(scenario_name=scen, num_envs=3, num_agents=64, world_size=30.0, episode_length=4, seed=3), 9, seed=8)
 
 
 def test_july_small_config_c1():
@@ -373,7 +377,7 @@ def test_step_many_equals_host_loop():
 
 
 @pytest.mark.parametrize("G,B", [(2, 64), (6, 128), (3, 256)])
-@pytest.mark.parametrize("scen", ["nav_metered_one_goal_graph_rotate_tube_july", "navigation_graph", ROT])
+@pytest.mark.parametrize("scen", ["nav_metered_one_goal_graph_rotate_tube_july", "navigation_graph"] + ROTFAM)
 def test_packed_tiles_with_staggered_resets_vs_oracle(monkeypatch, G, B, scen):
     """Several envs per workgroup, and envs of one tile resetting at DIFFERENT steps (mixed tiles):
     the episode clocks are staggered through set_field so that resets are not simultaneous."""

@@ -119,6 +119,9 @@ def test_config_from_args_mirrors_reference_fields():
         gmpe.config_from_args(a)
     a.use_safety_filter = False
     a.scenario_name = "two_phase_graph"
+    c3 = gmpe.config_from_args(a)
+    assert (c3.obs_dim, c3.node_feats, c3.n_actions) == (15, 7, 25)
+    a.scenario_name = "nav_metered_one_goal_graph_sequential_split_tube"      # a scenario file this engine does not build
     with pytest.raises(NotImplementedError):
         gmpe.config_from_args(a)
     c2 = gmpe.make_config(scenario_name="navigation_graph", num_agents=32, num_obstacles=8, num_walls=4, world_size=8.0)
@@ -271,5 +274,5 @@ def test_kernels_do_not_spill():
     txt = out.stdout + out.stderr
     names = re.findall(r"Function Name: (\S*k_env\S*)", txt)
     scratch = re.findall(r"Function Name: \S*k_env\S*.*?ScratchSize \[bytes/lane\]: (\d+)", txt, flags=re.S)
-    assert len(names) >= 36 and len(scratch) == len(names)      # 4 scenario variants x 3 tile shapes x 3 exact sizes
+    assert len(names) >= 54 and len(scratch) == len(names)      # 6 scenario variants x 3 tile shapes x 3 exact sizes
     assert all(int(x) == 0 for x in scratch), list(zip(names, scratch))
