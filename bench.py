@@ -35,6 +35,10 @@ WORKLOADS = {
     "c3r": dict(name="nav_graph_metered_single_corridor_rot_inv (air_taxi) 10 agents, 4096 vec envs",
                 scenario_name="nav_graph_metered_single_corridor_rot_inv", num_agents=10, num_obstacles=0,
                 num_walls=0, world_size=4.0, episode_length=25, envs=4096),
+    "c3p2": dict(name="two_phase_graph (air_taxi) 10 agents, 4096 vec envs",
+                 scenario_name="two_phase_graph", num_agents=10, num_obstacles=0, num_walls=0, world_size=4.0, episode_length=25, envs=4096),
+    "c3p3": dict(name="three_phase_graph (air_taxi) 10 agents, 4096 vec envs",
+                 scenario_name="three_phase_graph", num_agents=10, num_obstacles=0, num_walls=0, world_size=4.0, episode_length=25, envs=4096),
     # BASELINE.json configs[3] per-GPU shard and configs[4] per-GPU shard
     "c4": dict(name="navigation_graph 32 agents + 8 obstacles + 4 walls, 8192 envs sharded",
                scenario_name="navigation_graph", num_agents=32, num_obstacles=8, num_walls=4,
@@ -114,7 +118,7 @@ def main():
     torch.cuda.set_device(dev)
 
     wl = WORKLOADS[args.workload]
-    weak = args.workload in ("c2", "c3", "c3r")             # 4096 envs PER GPU; c4/c5 split a fixed total
+    weak = args.workload in ("c2", "c3", "c3r", "c3p2", "c3p3")             # 4096 envs PER GPU; c4/c5 split a fixed total
     n_envs = args.envs or (wl["envs"] if weak else wl["envs"] // world)
     # configs[1]/[2] are quoted per GPU (4096 envs on 1 MI355X): weak scaling keeps 4096 per GPU
     cfg = gmpe.make_config(scenario_name=wl["scenario_name"], num_envs=n_envs, num_agents=wl["num_agents"],

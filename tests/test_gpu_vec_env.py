@@ -99,6 +99,32 @@ def test_navigation_graph_vec_env():
     envs.close()
 
 
+@pytest.mark.parametrize("scen,D", [("nav_graph_metered_single_corridor_rot_inv", 13), ("two_phase_graph", 15), ("three_phase_graph", 15)])
+def test_shipped_weight_scenarios_vec_env(scen, D):
+    """The scenarios of model_weights/tube/** (SURVEY 8f rank 2): F = 7 node features, 18 info keys incl. Phase_reached."""
+    from gmpe.vec_env import make_train_env
+    from onpolicy_shapes import get_shape_from_obs_space
+    a = _args(scenario_name=scen, n_rollout_threads=24, episode_length=5)
+    envs = make_train_env(a)
+    N, A, E = 24, a.num_agents, 2 * a.num_agents
+    assert get_shape_from_obs_space(envs.observation_space[0]) == (D,)
+    assert get_shape_from_obs_space(envs.node_observation_space[0]) == (E, 7)
+    orc = ol.Oracle(envs.cfg)
+    obs, agent_id, node_obs, adj = envs.reset(); oo = orc.reset()
+    assert obs.shape == (N, A, D) and node_obs.shape == (N, A, E, 7)
+    np.testing.assert_allclose(obs, oo[0], atol=1e-5); np.testing.assert_allclose(node_obs, oo[2], atol=1e-5)
+    rng = np.random.RandomState(1)
+    for step in range(12):
+        actions = rng.randint(0, 25, (N, A))
+        obs, agent_id, node_obs, adj, rewards, dones, infos = envs.step(np.eye(25)[actions], step)
+        oo = orc.step(actions)
+        np.testing.assert_allclose(obs, oo[0], atol=1e-5); np.testing.assert_allclose(node_obs, oo[2], atol=1e-5)
+        np.testing.assert_allclose(rewards, oo[4], atol=1e-5); np.testing.assert_array_equal(dones, oo[5])
+    assert "Phase_reached" in infos[0][0] and len(infos[0][0]) == 18
+    np.testing.assert_allclose(infos.as_array(), oo[6], rtol=2e-6, atol=2e-5)
+    envs.close()
+
+
 def test_returned_arrays_stay_valid_for_one_more_step():
     """Pinned staging is double-buffered: what step t returned is untouched by step t+1."""
     from gmpe.vec_env import BatchedGraphMPEVecEnv
