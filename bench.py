@@ -199,6 +199,13 @@ def main():
                 traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        fill = None                                    # what a pure streaming-store kernel reaches on this part (tools_fillbw.hip)
+        fj = os.path.join(ROOT, "profiles", "r01_fillbw.json")
+        if os.path.exists(fj):
+            try:
+                fill = json.load(open(fj))["fill_GBps"]["98MB" if B * n_envs < (512 << 20) else "6GB"]
+            except Exception:
+                fill = None
         out = {
             "metric": "env-steps/sec (whole node) at 4096 envs x 10 agents, navigation_graph",
             "value": world * n_envs * K / el, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -210,6 +217,7 @@ def main():
                        "info": not args.no_info, "sharding": "env ranges, %d per GPU, no collective in step" % n_envs},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "measured_fill_peak": fill, "frac_of_measured_fill": (achieved / fill) if fill else None,
                          "kernel": "gmpe::k_env", "avg_launch_ms": avg_ms, "launches": launches,
                          "timing": "one HIP event pair on the launch stream around the K launches of the timed region",
                          "isolated_launch_ms": iso_ms / max(1, iso_n),

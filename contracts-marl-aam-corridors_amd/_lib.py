@@ -5,7 +5,8 @@ import os
 from .config import GmpeConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgmpe.so")
+# GMPE_LIB: diagnostic override to A/B another build of the SAME library (tools_*.py); never a fallback
+LIB_PATH = os.environ.get("GMPE_LIB") or os.path.join(_HERE, "libgmpe.so")
 _lib = None
 
 SYMBOLS = ["gmpe_abi_version", "gmpe_last_error", "gmpe_obs_dim", "gmpe_node_feats", "gmpe_num_entities", "gmpe_create",

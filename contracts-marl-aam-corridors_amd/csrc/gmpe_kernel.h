@@ -37,7 +37,7 @@ struct KParams {
     int nt;                   // 1: nontemporal graph stores (outputs per launch exceed the 256 MiB Infinity Cache)
     int ablate;               // debug: timing-only builds of the kernel skip parts (GMPE_ABLATE)
     // magic multipliers for exact unsigned division by run-time constants (q < 2^22): floor(q/d) = umulhi(q, m)
-    uint32_t m_E, m_AE, m_EE, m_nq, m_2E, m_pe, m_AD, m_A, m_L, m_O, m_S, m_SS, m_C, m_AC, m_AEE, m_W, m_Sx, m_FW;
+    uint32_t m_E, m_AE, m_EE, m_nq, m_2E, m_pe, m_AD, m_A, m_L, m_O, m_C, m_AC, m_AEE, m_W, m_Sx, m_FW;
     unsigned long long* stamps;   // diagnostic build only (-DGMPE_STAMPS): [grid][16] s_memtime per phase
 };
 __host__ __device__ inline uint32_t magic_of(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(0x100000000ull / d) + 1u; }
@@ -343,57 +343,54 @@ __device__ __forceinline__ void reset_world_serial(const KParams& p, const Lds& 
 
 // Post-move distance pass for every env of the tile (World.calculate_distances, core.py:600-624:
 // delta taken as pos[min]-pos[max], so the matrix is exactly symmetric). Writes the fp64 agent rows
-// Dm[g][r][c] AND the unmasked fp32 matrix M (agent rows + their mirrored columns); the static
-// (landmark/obstacle) x (landmark/obstacle) block is filled by static_block().
+// Dm[g][r][c] (r < A) AND the whole unmasked fp32 matrix M, static (landmark / obstacle) block included.
 template <int BLOCK>
 __device__ __forceinline__ void distance_pass(const KParams& p, const Lds& l, int G, int tid, bool only_reset) {
+    // One lane per UNORDERED entity pair (r < c) — agent-agent, agent-static and static-static alike — U independent
+    // pairs per trip (the pass is a chain of dependent LDS reads + an fp64 sqrt: latency-bound with one wave per SIMD).
+    // Pair index without a table: E even: w = a*(E-1)+b, a < E/2: b >= a -> (a, b+1), else the folded row (E-1-a, E-a+b);
+    // E odd: w = a*((E-1)/2)+b -> (a, a+1+b mod E), the circulant enumeration. Each pair appears exactly once.
     const int A = p.A, E = p.E, AE = A * E, EE4 = (E * E + 3) / 4 * 4;
-    const int NP = A * (A - 1) / 2, S = E - A, AS = A * S, W = NP + AS;   // per env: agent pairs + agent x static entities
+    const int W = E * (E - 1) / 2;
+    const bool even = (E & 1) == 0;
+    const int dv = even ? E - 1 : (E - 1) / 2;
     const int total = G * W;
-    for (int q0 = tid; q0 < total; q0 += 2 * BLOCK) {                   // two independent entries per trip
-        double ds[2]; int gs[2], rs[2], cs[2];
+    constexpr int U = 5;                                                // C2/C3 tile: 6 envs x 190 pairs = 1140 <= 5 x 256: one trip
+    for (int q0 = tid; q0 < total; q0 += U * BLOCK) {
+        double ds[U]; int gs[U], rs[U], cs[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int q = q0 + u * BLOCK;
             const bool live = q < total;
-            const int qq = live ? q : tid;
+            const int qq = live ? q : 0;
             const int g = fdiv(qq, W, p.m_W), w = qq - g * W;
-            const bool ap_ = w < NP;
-            const int pk = l.ptab[ap_ ? w : 0];
-            const int t = ap_ ? 0 : w - NP;
-            const int ro = fdiv(t, S, p.m_Sx);
-            const int r = ap_ ? (pk >> 8) : ro, cc = ap_ ? (pk & 255) : A + (t - ro * S);   // r < cc always
-            const double dx = l.ex[g * E + r] - l.ex[g * E + cc], dy = l.ey[g * E + r] - l.ey[g * E + cc];
+            const int a = fdiv(w, dv, p.m_Sx), b = w - a * dv;
+            int r, cc;
+            if (even) { const bool up = b >= a; r = up ? a : E - 1 - a; cc = up ? b + 1 : E - a + b; }
+            else { int c0 = a + 1 + b; c0 = c0 >= E ? c0 - E : c0; r = a < c0 ? a : c0; cc = a < c0 ? c0 : a; }
+            const double dx = l.ex[g * E + r] - l.ex[g * E + cc], dy = l.ey[g * E + r] - l.ey[g * E + cc];   // pos[min] - pos[max] (core.py:600-624)
             ds[u] = sqrt(dx * dx + dy * dy);
             gs[u] = (live && !(only_reset && !l.flags[g * 4 + 0])) ? g : -1; rs[u] = r; cs[u] = cc;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (gs[u] < 0) continue;
             const int r = rs[u], cc = cs[u];
-            double* Dg = l.Dm + (size_t)gs[u] * AE;
             float* Mg = l.M + (size_t)gs[u] * EE4;
             const float df = (float)ds[u];
-            Dg[r * E + cc] = ds[u]; Mg[r * E + cc] = df; Mg[cc * E + r] = df;
-            if (cc < A) Dg[cc * E + r] = ds[u];
+            Mg[r * E + cc] = df; Mg[cc * E + r] = df;
+            if (r < A) {
+                double* Dg = l.Dm + (size_t)gs[u] * AE;
+                Dg[r * E + cc] = ds[u];
+                if (cc < A) Dg[cc * E + r] = ds[u];
+            }
         }
     }
-    for (int q = tid; q < G * A; q += BLOCK) {                           // diagonal
-        const int g = fdiv(q, A, p.m_A), r = q - g * A;
+    for (int q = tid; q < G * E; q += BLOCK) {                           // diagonal
+        const int g = fdiv(q, E, p.m_E), r = q - g * E;
         if (only_reset && !l.flags[g * 4 + 0]) continue;
-        l.Dm[(size_t)g * AE + r * E + r] = 0.0; l.M[(size_t)g * EE4 + r * E + r] = 0.0f;
-    }
-}
-template <int BLOCK>
-__device__ __forceinline__ void static_block(const KParams& p, const Lds& l, int G, int tid, bool only_reset) {
-    const int A = p.A, E = p.E, S = p.L + p.O, SS = S * S, EE4 = (E * E + 3) / 4 * 4;
-    for (int q = tid; q < G * SS; q += BLOCK) {
-        const int g = fdiv(q, SS, p.m_SS), rc = q - g * SS, r3 = fdiv(rc, S, p.m_S), c3 = rc - r3 * S;
-        if (only_reset && !l.flags[g * 4 + 0]) continue;
-        const int r = A + r3, cc = A + c3;
-        const int a = r < cc ? r : cc, b = r < cc ? cc : r;
-        const double dx = l.ex[g * E + a] - l.ex[g * E + b], dy = l.ey[g * E + a] - l.ey[g * E + b];
-        l.M[(size_t)g * EE4 + r * E + cc] = r != cc ? (float)sqrt(dx * dx + dy * dy) : 0.0f;
+        l.M[(size_t)g * EE4 + r * E + r] = 0.0f;
+        if (r < A) l.Dm[(size_t)g * AE + r * E + r] = 0.0;
     }
 }
 
@@ -654,20 +651,30 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
             // ---- 1a. contact forces, one PAIR per lane (get_entity_collision_force core.py:872-906): pair (a, k>a)
             // computed once with delta = pos[a]-pos[k]; side a gets +F, side k gets -F (summed in 1b).
             const int NP = A * (A - 1) / 2, W = NP + A * O;            // valid pairs only: agent pairs (a<k) + agent x obstacle
-            for (int q = tid; q < Gv * W; q += BLOCK) {
-                const int gg = fdiv(q, W, p.m_FW), w = q - gg * W;
-                int a, kk;
-                if (w < NP) { const int pk = l.ptab[w]; a = pk >> 8; kk = pk & 255; }
-                else { const int t = w - NP; a = fdiv(t, O, p.m_O); kk = A + (t - a * O); }
-                const int k = kk < A ? kk : L + kk;                     // entity index of collider kk
-                const double dx = l.ex[gg * E + a] - l.ex[gg * E + k], dy = l.ey[gg * E + a] - l.ey[gg * E + k];
-                const double dist = sqrt(dx * dx + dy * dy);
-                double fx = 0.0, fy = 0.0;
-                if (dist < c.sep_dist + 50.0 * c.contact_margin) {      // else softplus < 1e-21: below one ulp of the sum
+            for (int q0 = tid; q0 < Gv * W; q0 += 2 * BLOCK) {          // two independent pairs per trip
+                double fxs[2], fys[2]; int slot[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int q = q0 + u * BLOCK;
+                    const bool live = q < Gv * W;
+                    const int qq = live ? q : 0;
+                    const int gg = fdiv(qq, W, p.m_FW), w = qq - gg * W;
+                    const bool apair = w < NP;
+                    const int pk = l.ptab[apair ? w : 0];
+                    const int t = apair ? 0 : w - NP;
+                    const int ao = fdiv(t, O, p.m_O);
+                    const int a = apair ? (pk >> 8) : ao, kk = apair ? (pk & 255) : A + (t - ao * O);
+                    const int k = kk < A ? kk : L + kk;                 // entity index of collider kk
+                    const double dx = l.ex[gg * E + a] - l.ex[gg * E + k], dy = l.ey[gg * E + a] - l.ey[gg * E + k];
+                    const double dist = sqrt(dx * dx + dy * dy);
+                    // branch-free: nearly every wave holds a pair inside the softplus range, so a per-lane skip only
+                    // serialises the two entries; far pairs get pen = log1p(exp(-large)) = 0 like in the reference
                     const double pen = logaddexp0(-(dist - c.sep_dist) / c.contact_margin) * c.contact_margin;
-                    fx = c.contact_force * dx / dist * pen; fy = c.contact_force * dy / dist * pen;
+                    fxs[u] = c.contact_force * dx / dist * pen; fys[u] = c.contact_force * dy / dist * pen;
+                    slot[u] = live ? gg * A * C + a * C + kk : -1;
                 }
-                Fx[(size_t)gg * A * C + a * C + kk] = fx; Fy[(size_t)gg * A * C + a * C + kk] = fy;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) if (slot[u] >= 0) { Fx[slot[u]] = fxs[u]; Fy[slot[u]] = fys[u]; }
             }
             __syncthreads();
         }
@@ -736,7 +743,6 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
         __syncthreads();
         STAMP(3);
         distance_pass<BLOCK>(p, l, Gv, tid, false);                    // post-move rows: obs, reward, info, adj all read these
-        static_block<BLOCK>(p, l, Gv, tid, false);
         __syncthreads();
         STAMP(4);
 
@@ -1099,7 +1105,6 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
             }
             __syncthreads();                                                // positions of all agents final
             distance_pass<BLOCK>(p, l, Gv, tid, true);
-            static_block<BLOCK>(p, l, Gv, tid, true);
             __syncthreads();
             if (mine) { if (rotfam) write_obs_rot<AP, SC>(p, v, i, ph1); else write_obs<AP, SC>(p, v, i, v.vox[i], v.voy[i], ph1); }
             any_mask = 0;

@@ -364,9 +364,10 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
     p.m_E = magic_of(p.E); p.m_AE = magic_of(p.A * p.E); p.m_EE = magic_of(p.E * p.E); p.m_nq = magic_of(p.E * p.E / 4);
     p.m_2E = magic_of(2 * p.E); p.m_pe = magic_of(p.A * p.E * 2); p.m_AD = magic_of(p.A * p.D); p.m_A = magic_of(p.A);
     p.m_L = magic_of(p.L); p.m_O = magic_of(p.O);
-    p.m_S = magic_of(p.L + p.O); p.m_SS = magic_of((p.L + p.O) * (p.L + p.O)); p.m_C = magic_of(p.A + p.O);
+    p.m_C = magic_of(p.A + p.O);
     p.m_AC = magic_of(p.A * (p.A + p.O)); p.m_AEE = magic_of(p.A * p.E * p.E);
-    p.m_W = magic_of(p.A * (p.A - 1) / 2 + p.A * (p.E - p.A)); p.m_Sx = magic_of(p.E - p.A); p.m_FW = magic_of(p.A * (p.A - 1) / 2 + p.A * p.O);
+    p.m_W = magic_of(p.E * (p.E - 1) / 2); p.m_Sx = magic_of((p.E & 1) ? (p.E - 1) / 2 : p.E - 1);      // distance_pass: pairs per env, inner divisor
+    p.m_FW = magic_of(p.A * (p.A - 1) / 2 + p.A * p.O);
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t lds = lds_bytes(h->G, h->A, h->E, h->D);
