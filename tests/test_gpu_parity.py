@@ -197,6 +197,15 @@ def test_rotfam_three_agents_and_64_agents(scen):
     _rollout_vs_oracle(gmpe.make_config(scenario_name=scen, num_envs=3, num_agents=64, world_size=30.0, episode_length=4, seed=3), 9, seed=8)
 
 
+@pytest.mark.parametrize("scen", ["nav_metered_one_goal_graph_rotate_tube_july", "navigation_graph"] + ROTFAM)
+def test_more_landmarks_than_agents(scen):
+    """num_landmarks need not equal num_agents (…_july.py:274): extra landmarks are graph nodes only."""
+    cfg = gmpe.make_config(scenario_name=scen, num_envs=20, num_agents=3, num_landmarks=5, world_size=4.0, episode_length=7, seed=17,
+                           num_obstacles=1 if scen == "navigation_graph" else 0)
+    assert cfg.num_entities == (9 if scen == "navigation_graph" else 8)
+    _rollout_vs_oracle(cfg, 18, seed=9)
+
+
 def test_july_small_config_c1():
     cfg = gmpe.make_config(num_envs=3, num_agents=3, world_size=4.0, episode_length=25, seed=5)
     _rollout_vs_oracle(cfg, 30, seed=3)
