@@ -651,30 +651,22 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
             // ---- 1a. contact forces, one PAIR per lane (get_entity_collision_force core.py:872-906): pair (a, k>a)
             // computed once with delta = pos[a]-pos[k]; side a gets +F, side k gets -F (summed in 1b).
             const int NP = A * (A - 1) / 2, W = NP + A * O;            // valid pairs only: agent pairs (a<k) + agent x obstacle
-            for (int q0 = tid; q0 < Gv * W; q0 += 2 * BLOCK) {          // two independent pairs per trip
-                double fxs[2], fys[2]; int slot[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int q = q0 + u * BLOCK;
-                    const bool live = q < Gv * W;
-                    const int qq = live ? q : 0;
-                    const int gg = fdiv(qq, W, p.m_FW), w = qq - gg * W;
-                    const bool apair = w < NP;
-                    const int pk = l.ptab[apair ? w : 0];
-                    const int t = apair ? 0 : w - NP;
-                    const int ao = fdiv(t, O, p.m_O);
-                    const int a = apair ? (pk >> 8) : ao, kk = apair ? (pk & 255) : A + (t - ao * O);
-                    const int k = kk < A ? kk : L + kk;                 // entity index of collider kk
-                    const double dx = l.ex[gg * E + a] - l.ex[gg * E + k], dy = l.ey[gg * E + a] - l.ey[gg * E + k];
-                    const double dist = sqrt(dx * dx + dy * dy);
-                    // branch-free: nearly every wave holds a pair inside the softplus range, so a per-lane skip only
-                    // serialises the two entries; far pairs get pen = log1p(exp(-large)) = 0 like in the reference
-                    const double pen = logaddexp0(-(dist - c.sep_dist) / c.contact_margin) * c.contact_margin;
-                    fxs[u] = c.contact_force * dx / dist * pen; fys[u] = c.contact_force * dy / dist * pen;
-                    slot[u] = live ? gg * A * C + a * C + kk : -1;
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) if (slot[u] >= 0) { Fx[slot[u]] = fxs[u]; Fy[slot[u]] = fys[u]; }
+            // One pair per lane and trip; only the waves that still own a pair run another trip (C2: 270 pairs on 256 lanes —
+            // the 14-pair tail costs one wave, not four). Branch-free: nearly every wave holds a pair inside the softplus
+            // range; far pairs get pen = log1p(exp(-large)) = 0 like in the reference.
+            for (int q = tid; q < Gv * W; q += BLOCK) {
+                const int gg = fdiv(q, W, p.m_FW), w = q - gg * W;
+                const bool apair = w < NP;
+                const int pk = l.ptab[apair ? w : 0];
+                const int t = apair ? 0 : w - NP;
+                const int ao = fdiv(t, O, p.m_O);
+                const int a = apair ? (pk >> 8) : ao, kk = apair ? (pk & 255) : A + (t - ao * O);
+                const int k = kk < A ? kk : L + kk;                     // entity index of collider kk
+                const double dx = l.ex[gg * E + a] - l.ex[gg * E + k], dy = l.ey[gg * E + a] - l.ey[gg * E + k];
+                const double dist = sqrt(dx * dx + dy * dy);
+                const double pen = logaddexp0(-(dist - c.sep_dist) / c.contact_margin) * c.contact_margin;
+                const int slot = gg * A * C + a * C + kk;
+                Fx[slot] = c.contact_force * dx / dist * pen; Fy[slot] = c.contact_force * dy / dist * pen;
             }
             __syncthreads();
         }
