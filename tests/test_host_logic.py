@@ -88,6 +88,16 @@ def test_create_without_gpu_fails_loudly():
         GmpeEngine(cfg)
 
 
+def test_bench_refuses_to_run_without_a_gpu():
+    """No CPU fallback anywhere on the product path: bench.py must fail, not time the oracle, when no GPU is visible."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and not any(ln.startswith("{") for ln in out.stdout.splitlines())
+
+
 def test_create_rejects_bad_configs():
     lib = _load_so()
     lib.gmpe_last_error.restype = C.c_char_p
