@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--no-info", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-loop", action="store_true", help="call gmpe_step from Python once per step instead of gmpe_step_many")
+    ap.add_argument("--no-graph", action="store_true", help="plain launch loop inside gmpe_step_many instead of the prepared hipGraph")
     ap.add_argument("--gather", action="store_true", help="also time step + RCCL all_gather of the compact rollout slab")
     args = ap.parse_args()
 
@@ -134,6 +135,13 @@ def main():
     eng.reset()
     for k in range(W):
         eng.step(actions[k % n_act_sets])
+    graph_ok = False
+    if not args.host_loop and not args.no_graph:
+        try:
+            eng.step_many_prepare(actions, K)    # capture + instantiate the K-launch hipGraph: setup, outside the timed region
+            graph_ok = True
+        except Exception as e:                   # same kernels either way: without a graph gmpe_step_many loops over plain launches
+            print("bench.py: hipGraph capture unavailable (%s); using the launch loop" % e, file=sys.stderr)
     torch.cuda.synchronize(dev)
 
     def barrier():
@@ -214,7 +222,9 @@ def main():
             "config": {"workload": wl["name"], "key": args.workload, "envs_per_gpu": n_envs,
                        "agents": cfg.num_agents, "entities": cfg.num_entities, "obs_dim": cfg.obs_dim,
                        "episode_length": cfg.episode_length, "adj": "compact [N,E,E]" if args.adj_compact else "materialised [N,A,E,E]",
-                       "info": not args.no_info, "sharding": "env ranges, %d per GPU, no collective in step" % n_envs},
+                       "info": not args.no_info,
+                       "launch": "host loop" if args.host_loop else ("hipGraph of K kernel nodes (gmpe_step_many_prepare)" if graph_ok else "launch loop in gmpe_step_many"),
+                       "sharding": "env ranges, %d per GPU, no collective in step" % n_envs},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "measured_fill_peak": fill, "frac_of_measured_fill": (achieved / fill) if fill else None,

@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("GMPE_LIB") or os.path.join(_HERE, "libgmpe.so")
 _lib = None
 
 SYMBOLS = ["gmpe_abi_version", "gmpe_last_error", "gmpe_obs_dim", "gmpe_node_feats", "gmpe_num_entities", "gmpe_create",
-           "gmpe_destroy", "gmpe_set_rng_tape", "gmpe_reset", "gmpe_step", "gmpe_step_many", "gmpe_step_onehot",
+           "gmpe_destroy", "gmpe_set_rng_tape", "gmpe_reset", "gmpe_step", "gmpe_step_many", "gmpe_step_many_prepare", "gmpe_step_onehot",
            "gmpe_field_bytes", "gmpe_get_field", "gmpe_set_field", "gmpe_edges_from_adj",
            "gmpe_timing_enable", "gmpe_timing_read", "gmpe_timing_mark", "gmpe_timing_region_ms"]
 
@@ -48,6 +48,7 @@ def load():
     lib.gmpe_step.argtypes = [P, P, C.POINTER(GmpeOutputs), P]
     lib.gmpe_step_onehot.argtypes = [P, P, C.POINTER(GmpeOutputs), P]
     lib.gmpe_step_many.argtypes = [P, P, C.c_int32, C.c_int32, C.POINTER(GmpeOutputs), P]
+    lib.gmpe_step_many_prepare.argtypes = [P, P, C.c_int32, C.c_int32, C.POINTER(GmpeOutputs)]
     lib.gmpe_field_bytes.argtypes = [P, I, C.POINTER(C.c_size_t)]
     lib.gmpe_get_field.argtypes = [P, I, P, C.c_size_t]
     lib.gmpe_set_field.argtypes = [P, I, P, C.c_size_t]

@@ -108,6 +108,11 @@ struct gmpe_handle {
     hipEvent_t region_ev[2] = {nullptr, nullptr};
     int32_t* edge_ws = nullptr;      // [cap_graphs] counts | [cap_graphs] offsets | [cap_graphs/1024+2] chunk sums
     size_t edge_ws_graphs = 0;
+    // hipGraphs of open-loop rollouts (gmpe_step_many_prepare): K kernel nodes replayed by one hipGraphLaunch
+    struct StepGraph { const int32_t* actions; int32_t K, S; gmpe_outputs out; hipGraph_t graph; hipGraphExec_t exec; };
+    std::vector<StepGraph> graphs;
+    hipStream_t cap_stream = nullptr;   // capture happens on a private stream (the caller's may be the legacy default stream)
+    bool capturing = false;
 };
 
 static thread_local std::string g_err;
@@ -310,6 +315,7 @@ int gmpe_debug_stamps(gmpe_handle* h, unsigned long long* host_dst, int64_t max_
 #endif
 
 int gmpe_destroy(gmpe_handle* h) {
+    if (h) { for (auto& g : h->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); } h->graphs.clear(); if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream); h->cap_stream = nullptr; }
     if (!h) return GMPE_OK;
     (void)hipSetDevice(h->device);
     for (void* q : h->allocs) (void)hipFree(q);
@@ -373,7 +379,7 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
     const size_t lds = lds_bytes(h->G, h->A, h->E, h->D);
     const dim3 grid((h->c.num_envs + h->G - 1) / h->G);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->timing) {
+    if (h->timing && !h->capturing) {
         if (h->ev_used + 2 > h->ev.size()) {
             for (int q = 0; q < 2; ++q) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->ev.push_back(e); }
         }
@@ -390,7 +396,7 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
         default: launch_env<SC_THREE>(h->block, ap, grid, lds, st, p); break;
     }
     HIPCHK(hipGetLastError());
-    if (h->timing) { HIPCHK(hipEventRecord(e1, st)); h->ev_used += 2; }
+    if (h->timing && !h->capturing) { HIPCHK(hipEventRecord(e1, st)); h->ev_used += 2; }
     return GMPE_OK;
 }
 
@@ -401,9 +407,55 @@ int gmpe_step(gmpe_handle* h, const int32_t* action_idx_dev, const gmpe_outputs*
     if (!action_idx_dev) return fail(GMPE_ERR_INVALID_ARG, "gmpe_step: null actions");
     return launch(h, MODE_STEP, action_idx_dev, nullptr, nullptr, out, stream);
 }
+static bool same_out(const gmpe_outputs& a, const gmpe_outputs& b) {
+    return a.obs == b.obs && a.agent_id == b.agent_id && a.node_obs == b.node_obs && a.adj == b.adj && a.reward == b.reward &&
+           a.done == b.done && a.info == b.info && a.adj_compact == b.adj_compact;
+}
+static int find_graph(const gmpe_handle* h, const int32_t* actions_dev, int32_t K, int32_t S, const gmpe_outputs& o) {
+    for (size_t q = 0; q < h->graphs.size(); ++q) {
+        const auto& g = h->graphs[q];
+        if (g.actions == actions_dev && g.K == K && g.S == S && same_out(g.out, o)) return (int)q;
+    }
+    return -1;
+}
+int gmpe_step_many_prepare(gmpe_handle* h, const int32_t* actions_dev, int32_t num_steps, int32_t num_action_sets, const gmpe_outputs* out) {
+    if (!h || !actions_dev || num_steps < 1 || num_action_sets < 1) return fail(GMPE_ERR_INVALID_ARG, "gmpe_step_many_prepare: bad arguments");
+    gmpe_outputs o; memset(&o, 0, sizeof o); if (out) o = *out;
+    if (find_graph(h, actions_dev, num_steps, num_action_sets, o) >= 0) return GMPE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->cap_stream) HIPCHK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    if (h->graphs.size() >= 4) {                                  // small cache: drop the oldest
+        (void)hipGraphExecDestroy(h->graphs[0].exec); (void)hipGraphDestroy(h->graphs[0].graph);
+        h->graphs.erase(h->graphs.begin());
+    }
+    gmpe_handle::StepGraph g; g.actions = actions_dev; g.K = num_steps; g.S = num_action_sets; g.out = o; g.graph = nullptr; g.exec = nullptr;
+    HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+    h->capturing = true;
+    const size_t stride = (size_t)h->c.num_envs * h->A;
+    int rc = GMPE_OK;
+    for (int32_t k = 0; k < num_steps && rc == GMPE_OK; ++k)
+        rc = launch(h, MODE_STEP, actions_dev + (size_t)(k % num_action_sets) * stride, nullptr, nullptr, out, h->cap_stream);
+    h->capturing = false;
+    const hipError_t e = hipStreamEndCapture(h->cap_stream, &g.graph);
+    if (rc) { if (g.graph) (void)hipGraphDestroy(g.graph); return rc; }
+    if (e != hipSuccess) return fail(GMPE_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    const hipError_t e2 = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+    if (e2 != hipSuccess) { (void)hipGraphDestroy(g.graph); return fail(GMPE_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2)); }
+    h->graphs.push_back(g);
+    return GMPE_OK;
+}
 int gmpe_step_many(gmpe_handle* h, const int32_t* actions_dev, int32_t num_steps, int32_t num_action_sets,
                    const gmpe_outputs* out, void* stream) {
-    if (!actions_dev || num_steps < 0 || num_action_sets < 1) return fail(GMPE_ERR_INVALID_ARG, "gmpe_step_many: bad arguments");
+    if (!h || !actions_dev || num_steps < 0 || num_action_sets < 1) return fail(GMPE_ERR_INVALID_ARG, "gmpe_step_many: bad arguments");
+    if (!h->timing) {                                             // per-launch event pairs need individual launches
+        gmpe_outputs o; memset(&o, 0, sizeof o); if (out) o = *out;
+        const int q = find_graph(h, actions_dev, num_steps, num_action_sets, o);
+        if (q >= 0) {                                             // prepared: one graph launch replays the K kernel nodes
+            HIPCHK(hipSetDevice(h->device));
+            HIPCHK(hipGraphLaunch(h->graphs[q].exec, static_cast<hipStream_t>(stream)));
+            return GMPE_OK;
+        }
+    }
     const size_t stride = (size_t)h->c.num_envs * h->A;
     for (int32_t k = 0; k < num_steps; ++k) {
         const int rc = launch(h, MODE_STEP, actions_dev + (size_t)(k % num_action_sets) * stride, nullptr, nullptr, out, stream);

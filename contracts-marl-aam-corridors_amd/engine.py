@@ -99,14 +99,24 @@ class GmpeEngine(object):
         _lib.check(self.lib.gmpe_step(self.h, a.data_ptr(), C.byref(self._o), self._stream()), "gmpe_step")
         return self.out
 
-    def step_many(self, action_sets, num_steps):
-        """Open-loop rollout: `num_steps` steps enqueued by one C call; step k uses action_sets[k % len]
-        (int32 device tensor [S, N, A]). Returns the outputs of the LAST step."""
-        a = action_sets
+    def _check_action_sets(self, a):
         if a.dtype != torch.int32 or not a.is_contiguous() or a.device != self.device or a.dim() != 3:
             raise ValueError("action_sets must be a contiguous int32 device tensor [S, N, A]")
         if a.shape[1] * a.shape[2] != self.N * self.A:
             raise ValueError("action_sets must be [S, %d, %d]" % (self.N, self.A))
+
+    def step_many_prepare(self, action_sets, num_steps):
+        """Record the launches of step_many(action_sets, num_steps) into a hipGraph (once, off the step path); later
+        step_many calls with the same tensor / count / outputs replay it with one graph launch."""
+        self._check_action_sets(action_sets)
+        _lib.check(self.lib.gmpe_step_many_prepare(self.h, action_sets.data_ptr(), int(num_steps), int(action_sets.shape[0]),
+                                                   C.byref(self._o)), "gmpe_step_many_prepare")
+
+    def step_many(self, action_sets, num_steps):
+        """Open-loop rollout: `num_steps` steps enqueued by one C call; step k uses action_sets[k % len]
+        (int32 device tensor [S, N, A]). Returns the outputs of the LAST step."""
+        a = action_sets
+        self._check_action_sets(a)
         _lib.check(self.lib.gmpe_step_many(self.h, a.data_ptr(), int(num_steps), int(a.shape[0]), C.byref(self._o),
                                            self._stream()), "gmpe_step_many")
         return self.out

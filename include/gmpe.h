@@ -200,6 +200,14 @@ int gmpe_step(gmpe_handle* h, const int32_t* action_idx_dev, const gmpe_outputs*
 int gmpe_step_many(gmpe_handle* h, const int32_t* actions_dev, int32_t num_steps, int32_t num_action_sets,
                    const gmpe_outputs* out, void* stream);
 
+/* Optional: record the `num_steps` launches of gmpe_step_many(actions_dev, num_steps, num_action_sets, out) into a
+ * hipGraph once (capture on a private stream + instantiate: milliseconds, not on the step path). Later
+ * gmpe_step_many calls with the SAME pointers and counts replay it with one hipGraphLaunch on the caller's stream
+ * (kernel-to-kernel dispatch overhead 3.6 -> 1.6 us at this launch shape, profiles/README.md); any other call takes
+ * the plain launch loop. The action / output BUFFERS are baked in, their contents are read at replay time. */
+int gmpe_step_many_prepare(gmpe_handle* h, const int32_t* actions_dev, int32_t num_steps, int32_t num_action_sets,
+                           const gmpe_outputs* out);
+
 /* Same, taking the runner's float one-hot [N,A,n_actions] (graph_mpe_runner.py:375-377); the
  * argmax (np.argmax: first maximum) is fused into the step kernel. */
 int gmpe_step_onehot(gmpe_handle* h, const float* onehot_dev, const gmpe_outputs* out, void* stream);

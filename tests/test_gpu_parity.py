@@ -385,6 +385,31 @@ def test_step_many_equals_host_loop():
         np.testing.assert_array_equal(e1.get(f), e2.get(f))
 
 
+def test_step_many_hipgraph_replay_equals_host_loop():
+    """gmpe_step_many_prepare: the K launches recorded into a hipGraph, replayed twice (the action buffer's CONTENTS change
+    between the replays: the graph bakes in pointers, not data) == the same steps issued one by one."""
+    import torch
+    cfg = gmpe.make_config(num_envs=70, num_agents=10, seed=18, episode_length=9)
+    e1, e2 = _engine(cfg), _engine(cfg)
+    e1.reset(); e2.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(6)
+    acts = torch.randint(0, 25, (5, 70, 10), generator=g, device="cuda", dtype=torch.int32)
+    e2.step_many_prepare(acts, 12)
+    for rep in range(2):
+        for k in range(12):
+            o1 = e1.step(acts[k % 5])
+        o2 = e2.step_many(acts, 12)                      # prepared -> one hipGraphLaunch
+        torch.cuda.synchronize()
+        for k in ("obs", "node_obs", "adj", "reward", "done", "info"):
+            assert torch.equal(getattr(o1, k), getattr(o2, k)), k
+        _compare_state(e1, e2, "rep %d" % rep)
+        acts.copy_(torch.randint(0, 25, (5, 70, 10), generator=g, device="cuda", dtype=torch.int32))
+    o1 = [e1.step(acts[k % 5]) for k in range(7)][-1]
+    o2 = e2.step_many(acts, 7)                            # not prepared -> plain launch loop
+    assert torch.equal(o1.obs, o2.obs) and torch.equal(o1.adj, o2.adj)
+    e2.check_errors()
+
+
 @pytest.mark.parametrize("G,B", [(2, 64), (6, 128), (3, 256)])
 @pytest.mark.parametrize("scen", ["nav_metered_one_goal_graph_rotate_tube_july", "navigation_graph"] + ROTFAM)
 def test_packed_tiles_with_staggered_resets_vs_oracle(monkeypatch, G, B, scen):
