@@ -369,7 +369,7 @@ __device__ __forceinline__ void distance_pass(const KParams& p, const Lds& l, in
             if (even) { const bool up = b >= a; r = up ? a : E - 1 - a; cc = up ? b + 1 : E - a + b; }
             else { int c0 = a + 1 + b; c0 = c0 >= E ? c0 - E : c0; r = a < c0 ? a : c0; cc = a < c0 ? c0 : a; }
             const double dx = l.ex[g * E + r] - l.ex[g * E + cc], dy = l.ey[g * E + r] - l.ey[g * E + cc];   // pos[min] - pos[max] (core.py:600-624)
-            ds[u] = sqrt(dx * dx + dy * dy);
+            ds[u] = (p.ablate & 16) ? dx * dx + dy * dy : sqrt(dx * dx + dy * dy);   // 16: timing diagnostic only
             gs[u] = (live && !(only_reset && !l.flags[g * 4 + 0])) ? g : -1; rs[u] = r; cs[u] = cc;
         }
 #pragma unroll
@@ -655,6 +655,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
             // the 14-pair tail costs one wave, not four). Branch-free: nearly every wave holds a pair inside the softplus
             // range; far pairs get pen = log1p(exp(-large)) = 0 like in the reference.
             for (int q = tid; q < Gv * W; q += BLOCK) {
+                if (p.ablate & 8) { Fx[q] = 0.0; Fy[q] = 0.0; continue; }   // timing diagnostic only (wrong results)
                 const int gg = fdiv(q, W, p.m_FW), w = q - gg * W;
                 const bool apair = w < NP;
                 const int pk = l.ptab[apair ? w : 0];
