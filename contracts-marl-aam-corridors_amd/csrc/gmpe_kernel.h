@@ -57,6 +57,7 @@ struct Lds {
     double *rew;                      // [G][A]
     double *tube;                     // [G][12]
     double *Dm;                       // [G][A][E] fp64 agent->entity distances (rows of cached_dist_mag)
+    double *fw;                       // [G][A][2*NW] wall contact forces (x, y per wall), walls variant only
     int *s_old, *newf, *gt;           // [G][A]  status before, newly-reached flag, goal_tracker (final)
     int *dtg_o, *dtg_n, *trq_o, *trq_n, *sv_o, *sv_n;   // [G][A] info counters old/new
     int *flags;                       // [G][4]  0: reset this env, 1: heading draws this step, 2: env has masked nodes, 3: env active
@@ -65,14 +66,14 @@ struct Lds {
     float *obs;                       // [G][A*D] staging
     float *M;                         // [G][E*E] masked distance matrix, fp32
 };
-__host__ __device__ inline size_t lds_bytes(int G, int A, int E, int D) {
+__host__ __device__ inline size_t lds_bytes(int G, int A, int E, int D, int NW) {
     const size_t EE4 = ((size_t)E * E + 3) / 4 * 4, AD4 = ((size_t)A * D + 3) / 4 * 4;
-    size_t d = (size_t)G * (2 * E + 12 * A + 12 + (size_t)A * E);   // doubles
+    size_t d = (size_t)G * (2 * E + 12 * A + 12 + (size_t)A * E + (size_t)A * 2 * NW);   // doubles
     size_t f = (size_t)G * (EE4 + AD4);                             // floats
     size_t i = (size_t)G * (9 * A + 4 + E) + (size_t)A * (A - 1) / 2 + 1;   // ints
     return d * 8 + 16 + f * 4 + ((i * 4 + 15) / 16) * 16 + 32;
 }
-__device__ inline Lds carve(char* base, int G, int A, int E, int D) {
+__device__ inline Lds carve(char* base, int G, int A, int E, int D, int NW) {
     Lds l;
     double* d = reinterpret_cast<double*>(base);
     l.ex = d; d += G * E; l.ey = d; d += G * E;
@@ -80,6 +81,7 @@ __device__ inline Lds carve(char* base, int G, int A, int E, int D) {
     l.vox = d; d += G * A; l.voy = d; d += G * A; l.vnx = d; d += G * A; l.vny = d; d += G * A;
     l.serr = d; d += G * A; l.cn = d; d += G * A; l.sn = d; d += G * A; l.rew = d; d += G * A; l.tube = d; d += G * 12;
     l.Dm = d; d += (size_t)G * A * E;
+    l.fw = d; d += (size_t)G * A * 2 * NW;
     if ((uintptr_t)d & 15) d += 1;
     float* f = reinterpret_cast<float*>(d);
     const size_t EE4 = ((size_t)E * E + 3) / 4 * 4, AD4 = ((size_t)A * D + 3) / 4 * 4;
@@ -99,7 +101,7 @@ __device__ inline Lds env_view(const Lds& l, int g, int A, int E, int D) {
     v.s2 = l.s2 + g * A; v.s3 = l.s3 + g * A; v.n2 = l.n2 + g * A; v.n3 = l.n3 + g * A;
     v.vox = l.vox + g * A; v.voy = l.voy + g * A; v.vnx = l.vnx + g * A; v.vny = l.vny + g * A;
     v.serr = l.serr + g * A; v.cn = l.cn + g * A; v.sn = l.sn + g * A; v.rew = l.rew + g * A; v.tube = l.tube + g * 12;
-    v.Dm = l.Dm + (size_t)g * A * E;
+    v.Dm = l.Dm + (size_t)g * A * E; v.fw = l.fw;      // fw is indexed with the tile-level agent slot
     v.s_old = l.s_old + g * A; v.newf = l.newf + g * A; v.gt = l.gt + g * A;
     v.dtg_o = l.dtg_o + g * A; v.dtg_n = l.dtg_n + g * A; v.trq_o = l.trq_o + g * A; v.trq_n = l.trq_n + g * A;
     v.sv_o = l.sv_o + g * A; v.sv_n = l.sv_n + g * A; v.flags = l.flags + g * 4; v.moff = l.moff + g * E; v.ptab = l.ptab;
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
     const int tid = threadIdx.x;
     const int A = p.A, L = p.L, O = p.O, E = p.E, D = p.D, G = p.G, N = p.c.num_envs;
     const gmpe_config& c = p.c;
-    const Lds l = carve(smem, G, A, E, D);
+    const Lds l = carve(smem, G, A, E, D, SC == SC_NAV_WALLS ? p.c.num_walls : 0);
     const int n0 = blockIdx.x * G;
     const int Gv = min(G, N - n0);                                      // envs actually present in this tile
     constexpr bool july = SC == SC_JULY, rotinv = SC == SC_ROT, rotfam = sc_rotfam(SC), two = SC == SC_TWO, three = SC == SC_THREE;
@@ -596,12 +598,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
             st0 = p.s.status[na]; gt0 = p.s.goal_tracker[na];
             phase_reached = p.s.phase_reached[na]; cooldown = p.s.cooldown[na];
             p_dist = p.s.p_dist[na]; tim = p.s.time[na];
-            trq = p.s.times_required[na]; dtg = p.s.dists_to_goal[na]; dleft = p.s.dist_left[na];
-            greached = p.s.goal_reached[na]; nac = p.s.n_agent_coll[na]; noc = p.s.n_obst_coll[na];
-            sv = p.s.spacing_viol[na]; sic = p.s.steps_in_corr[na]; conf = p.s.conformance[na];
-            gmt = p.s.goal_min_time[na];
-            if (rotinv) pproj = p.s.prev_proj[na];
-            dsp0 = p.s.delta_spacing[n];
+            // (the info counters are loaded at the start of section 2: ~14 fewer registers live across the contact / distance phases)
             if (p.act) act_idx = p.act[na];
             else {                                                      // np.argmax: first maximum
                 const float* oh = p.onehot + na * c.n_actions;
@@ -669,6 +666,18 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
                 const int slot = gg * A * C + a * C + kk;
                 Fx[slot] = c.contact_force * dx / dist * pen; Fy[slot] = c.contact_force * dy / dist * pen;
             }
+            if (WALLS) {
+                // wall contact forces (get_wall_collision_force core.py:909-964), one (agent, wall) per lane: the asin / cos /
+                // softplus code lives here instead of in the agent lane's dynamics (187 -> 141 VGPRs for the walls variant)
+                const int NW = c.num_walls;
+                for (int q = tid; q < Gv * A * NW; q += BLOCK) {
+                    const int slot = q / NW, w = q - slot * NW;         // slot = tile-level agent index (gg*A + a)
+                    const int gg = fdiv(slot, A, p.m_A), a = slot - gg * A;
+                    double wx = 0.0, wy = 0.0;
+                    if (!wall_force(c.walls[w], l.ex[gg * E + a], l.ey[gg * E + a], c.entity_size, c.wall_contact_force, c.wall_contact_margin, wx, wy)) { wx = 0.0; wy = 0.0; }
+                    l.fw[(size_t)slot * 2 * NW + 2 * w] = wx; l.fw[(size_t)slot * 2 * NW + 2 * w + 1] = wy;   // None -> +0.0: x + 0.0 == x
+                }
+            }
             __syncthreads();
         }
         STAMP(2);
@@ -716,9 +725,9 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
                     const double fx = fxg[i * C + A + o], fy = fyg[i * C + A + o];
                     if (fx != 0.0 || fy != 0.0) { sx = fx + sx; sy = fy + sy; }
                 }
-                if (WALLS) for (int w = 0; w < c.num_walls; ++w) {
-                    double wx, wy;
-                    if (wall_force(c.walls[w], nx, ny, c.entity_size, c.wall_contact_force, c.wall_contact_margin, wx, wy)) { sx = sx + wx; sy = sy + wy; }
+                if (WALLS) {
+                    const double* fwi = l.fw + (size_t)(g * A + i) * 2 * c.num_walls;
+                    for (int w = 0; w < c.num_walls; ++w) { sx = sx + fwi[2 * w]; sy = sy + fwi[2 * w + 1]; }
                 }
                 double vx = nv2 * (1 - c.damping), vy = nv3 * (1 - c.damping);
                 vx += (sx / 1.0) * c.dt; vy += (sy / 1.0) * c.dt;
@@ -742,6 +751,14 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
         // ---- 2. phase FSM + who newly reaches the goal (depends only on own data: SURVEY §8a)
         prevA = prev_phase;
         if (ag) {
+            // info counters: issued HERE — after the register-hungry contact / distance phases, before the graph stores
+            // saturate HBM (a read issued under the drain takes microseconds) — and first used in section 3
+            trq = p.s.times_required[na]; dtg = p.s.dists_to_goal[na]; dleft = p.s.dist_left[na];
+            greached = p.s.goal_reached[na]; nac = p.s.n_agent_coll[na]; noc = p.s.n_obst_coll[na];
+            sv = p.s.spacing_viol[na]; sic = p.s.steps_in_corr[na]; conf = p.s.conformance[na];
+            gmt = p.s.goal_min_time[na];
+            if (rotinv) pproj = p.s.prev_proj[na];
+            dsp0 = p.s.delta_spacing[n];
             const double px = v.ex[i], py = v.ey[i];
             double vx, vy; vel_of<SC>(v.s2[i], v.s3[i], vx, vy);
             v.vox[i] = vx; v.voy[i] = vy;

@@ -263,7 +263,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     if (G > 64 / h->A) G = 64 / h->A;
     if (G < 1) G = 1;
     if (G > (int)N) G = (int)N;
-    while (G > 1 && lds_bytes(G, h->A, E, h->D) > 48 * 1024) --G;
+    while (G > 1 && lds_bytes(G, h->A, E, h->D, cfg->num_walls) > 48 * 1024) --G;
     {   // exact magic division (fdiv) needs q*d < 2^32 for every (range, divisor) pair the kernel uses
         const uint64_t S = (uint64_t)h->L + h->O;
         uint64_t d = (uint64_t)h->A * E;
@@ -286,7 +286,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     // Specialisation pays while the per-agent arithmetic is comparable to the tile's store work (C2/C3: 36.7 -> 33.4 us);
     // store-dominated tiles (C4/C5) want every wave on the stores (C4: 1337 us vs 1421 us specialised).
     h->spec = getenv("GMPE_SPEC") ? atoi(getenv("GMPE_SPEC")) : (stream_f4 <= 16384 ? 1 : 0);
-    const size_t lds = lds_bytes(h->G, h->A, E, h->D);
+    const size_t lds = lds_bytes(h->G, h->A, E, h->D, cfg->num_walls);
     if (lds > 160 * 1024) { gmpe_destroy(h); return fail(GMPE_ERR_UNSUPPORTED, "per-tile LDS exceeds 160 KiB"); }
     if (lds > 48 * 1024) {                                   // opt in to >64 KiB dynamic LDS (gfx950: 160 KiB per CU)
         const hipError_t e = sc_dispatch_lds(sc_of(h->c), (int)lds);
@@ -376,7 +376,7 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
     p.m_FW = magic_of(p.A * (p.A - 1) / 2 + p.A * p.O);
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t lds = lds_bytes(h->G, h->A, h->E, h->D);
+    const size_t lds = lds_bytes(h->G, h->A, h->E, h->D, h->c.num_walls);
     const dim3 grid((h->c.num_envs + h->G - 1) / h->G);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing && !h->capturing) {
