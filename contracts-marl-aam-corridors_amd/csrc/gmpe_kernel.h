@@ -546,7 +546,7 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, 
 // SC: scenario variant (above). Only SC_NAV_WALLS compiles the wall-contact code (asin / cos / softplus inside the agent lane's dynamics) out: it is
 // the single largest consumer of registers (187 -> 135 VGPRs), i.e. 2 -> 3 waves per SIMD for wall-less worlds.
 template <int BLOCK, int AP, int SC>
-__global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_MIN_WAVES_NOWALLS)) void k_env(const KParams p) {
+__global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP > 0 ? 4 : GMPE_MIN_WAVES_NOWALLS))) void k_env(const KParams p) {
     constexpr bool WALLS = SC == SC_NAV_WALLS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1142,5 +1142,6 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : GMPE_
 // Host entry points of one scenario variant; defined and explicitly instantiated in gmpe_sc.hip (-DGMPE_SC=k).
 template <int SC> void launch_env(int block, int ap, dim3 grid, size_t lds, hipStream_t st, const KParams& p);
 template <int SC> hipError_t set_max_lds(int lds);
+template <int SC> int max_tiles_per_cu(int block, int ap, size_t lds);
 
 }  // namespace gmpe

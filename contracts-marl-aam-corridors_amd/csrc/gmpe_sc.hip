@@ -34,7 +34,21 @@ hipError_t set_max_lds(int lds) {
     return e;
 }
 
+// resident workgroups per CU of the instantiation launch_env would pick (registers + LDS), 0 on error
+template <int SC>
+int max_tiles_per_cu(int block, int ap, size_t lds) {
+#define FN(B, P) reinterpret_cast<const void*>(&k_env<B, P, SC>)
+#define PICK(B) (ap == 10 ? FN(B, 10) : (ap == 3 ? FN(B, 3) : FN(B, 0)))
+    const void* fn = block == 64 ? PICK(64) : (block == 128 ? PICK(128) : PICK(256));
+#undef PICK
+#undef FN
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, block, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return nb;
+}
+
 template void launch_env<GMPE_SC>(int, int, dim3, size_t, hipStream_t, const KParams&);
+template int max_tiles_per_cu<GMPE_SC>(int, int, size_t);
 template hipError_t set_max_lds<GMPE_SC>(int);
 
 }  // namespace gmpe

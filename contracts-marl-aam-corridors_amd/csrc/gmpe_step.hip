@@ -138,6 +138,16 @@ static int sc_of(const gmpe_config& c) {
         default: return c.num_walls > 0 ? SC_NAV_WALLS : SC_NAV;
     }
 }
+static int sc_dispatch_occ(int sc, int block, int ap, size_t lds) {
+    switch (sc) {
+        case SC_NAV: return max_tiles_per_cu<SC_NAV>(block, ap, lds);
+        case SC_NAV_WALLS: return max_tiles_per_cu<SC_NAV_WALLS>(block, ap, lds);
+        case SC_JULY: return max_tiles_per_cu<SC_JULY>(block, ap, lds);
+        case SC_ROT: return max_tiles_per_cu<SC_ROT>(block, ap, lds);
+        case SC_TWO: return max_tiles_per_cu<SC_TWO>(block, ap, lds);
+        default: return max_tiles_per_cu<SC_THREE>(block, ap, lds);
+    }
+}
 static hipError_t sc_dispatch_lds(int sc, int lds) {
     switch (sc) {
         case SC_NAV: return set_max_lds<SC_NAV>(lds);
@@ -255,15 +265,33 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     // distance pass and the stores. GMPE_G / GMPE_BLOCK override the heuristic (tuning, tests).
     const char* env_g = getenv("GMPE_G");
     const char* env_block = getenv("GMPE_BLOCK");
-    // Heuristic (measured on MI355X, profiles/README.md): the per-agent passes are a dependent fp64 chain, so a tile packs
-    // as many envs as fit one wave (G*A <= 64) once there are enough tiles (~700) to cover the chip; multi-wave tiles
-    // specialise (wave 0: reward/info, waves 1..: graph stores). C2/C3: G = 6, BLOCK = 256 -> 683 tiles x 4 waves.
-    int G = env_g ? atoi(env_g) : (int)(N / 680);
-    if (G < 1) G = 1;
-    if (G > 64 / h->A) G = 64 / h->A;
-    if (G < 1) G = 1;
-    if (G > (int)N) G = (int)N;
-    while (G > 1 && lds_bytes(G, h->A, E, h->D, cfg->num_walls) > 48 * 1024) --G;
+    // Heuristic (measured on MI355X, profiles/README.md "tile shapes"): every tile should be RESIDENT at once (a second round of
+    // tiles repeats the whole latency chain), with about four tiles per CU — one wave-0 chain per SIMD — and as many waves per
+    // tile as still fit: C2/C3 pick G = 4, BLOCK = 256 (1024 tiles = 4 per CU x 4 waves at <= 128 VGPRs). Residency is asked
+    // from the runtime (registers + LDS of the instantiation that will run). When the batch cannot be resident at all
+    // (C4/C5, N >> 4096) a tile packs as many envs as wave 0 holds (G*A <= 64) and the stores decide.
+    int dev_cus = 256;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) dev_cus = prop.multiProcessorCount; }
+    int Gmax = 64 / h->A; if (Gmax < 1) Gmax = 1; if (Gmax > (int)N) Gmax = (int)N;
+    while (Gmax > 1 && lds_bytes(Gmax, h->A, E, h->D, cfg->num_walls) > 48 * 1024) --Gmax;
+    const int ap_sel = (h->A == h->L && (h->A == 10 || h->A == 3)) ? h->A : 0;
+    int G = 0, block_sel = 0;
+    if (!env_g && !env_block) {
+        int G0 = (int)((N + 4 * (size_t)dev_cus - 1) / (4 * (size_t)dev_cus));
+        if (G0 < 1) G0 = 1;
+        const int blocks[3] = {256, 128, 64};
+        for (int bi = 0; bi < 3 && !G; ++bi)
+            for (int g = G0; g <= Gmax; ++g) {
+                const size_t tiles = (N + g - 1) / g;
+                const int per_cu = sc_dispatch_occ(sc_of(h->c), blocks[bi], ap_sel, lds_bytes(g, h->A, E, h->D, cfg->num_walls));
+                if (per_cu > 0 && tiles <= (size_t)per_cu * dev_cus) { G = g; block_sel = blocks[bi]; break; }
+            }
+    }
+    if (!G) {
+        G = env_g ? atoi(env_g) : Gmax;
+        if (G < 1) G = 1;
+        if (G > Gmax) G = Gmax;
+    }
     {   // exact magic division (fdiv) needs q*d < 2^32 for every (range, divisor) pair the kernel uses
         const uint64_t S = (uint64_t)h->L + h->O;
         uint64_t d = (uint64_t)h->A * E;
@@ -281,7 +309,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
         h->nt = getenv("GMPE_NT") ? atoi(getenv("GMPE_NT")) : (out_bytes > 192.0 * 1024 * 1024 ? 1 : 0);
     }
     const size_t stream_f4 = (size_t)G * h->A * ((size_t)E * E / 4 + 2 * (size_t)E);
-    h->block = env_block ? atoi(env_block) : (stream_f4 <= 2048 ? 64 : (stream_f4 <= 6144 ? 128 : 256));
+    h->block = env_block ? atoi(env_block) : (block_sel ? block_sel : (stream_f4 <= 2048 ? 64 : (stream_f4 <= 6144 ? 128 : 256)));
     if (h->block != 64 && h->block != 128 && h->block != 256) h->block = 256;
     // Specialisation pays while the per-agent arithmetic is comparable to the tile's store work (C2/C3: 36.7 -> 33.4 us);
     // store-dominated tiles (C4/C5) want every wave on the stores (C4: 1337 us vs 1421 us specialised).
