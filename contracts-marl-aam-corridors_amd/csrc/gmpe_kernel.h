@@ -346,47 +346,61 @@ __device__ __forceinline__ void reset_world_serial(const KParams& p, const Lds& 
 // Post-move distance pass for every env of the tile (World.calculate_distances, core.py:600-624:
 // delta taken as pos[min]-pos[max], so the matrix is exactly symmetric). Writes the fp64 agent rows
 // Dm[g][r][c] (r < A) AND the whole unmasked fp32 matrix M, static (landmark / obstacle) block included.
+// U independent pairs of one lane (q0, q0+BLOCK, ...), interleaved: the pass is a chain of dependent LDS reads + an fp64 sqrt
+template <int BLOCK, int U>
+__device__ __forceinline__ void distance_trip(const KParams& p, const Lds& l, int q0, int total, int W, int dv, bool even, bool only_reset) {
+    const int A = p.A, E = p.E, AE = A * E, EE4 = (E * E + 3) / 4 * 4;
+    double ds[U]; int gs[U], rs[U], cs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int q = q0 + u * BLOCK;
+        const bool live = q < total;
+        const int qq = live ? q : 0;
+        const int g = fdiv(qq, W, p.m_W), w = qq - g * W;
+        const int a = fdiv(w, dv, p.m_Sx), b = w - a * dv;
+        int r, cc;
+        if (even) { const bool up = b >= a; r = up ? a : E - 1 - a; cc = up ? b + 1 : E - a + b; }
+        else { int c0 = a + 1 + b; c0 = c0 >= E ? c0 - E : c0; r = a < c0 ? a : c0; cc = a < c0 ? c0 : a; }
+        const double dx = l.ex[g * E + r] - l.ex[g * E + cc], dy = l.ey[g * E + r] - l.ey[g * E + cc];   // pos[min] - pos[max] (core.py:600-624)
+        ds[u] = (p.ablate & 16) ? dx * dx + dy * dy : sqrt(dx * dx + dy * dy);   // 16: timing diagnostic only
+        gs[u] = (live && !(only_reset && !l.flags[g * 4 + 0])) ? g : -1; rs[u] = r; cs[u] = cc;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (gs[u] < 0) continue;
+        const int r = rs[u], cc = cs[u];
+        float* Mg = l.M + (size_t)gs[u] * EE4;
+        const float df = (float)ds[u];
+        Mg[r * E + cc] = df; Mg[cc * E + r] = df;
+        if (r < A) {
+            double* Dg = l.Dm + (size_t)gs[u] * AE;
+            Dg[r * E + cc] = ds[u];
+            if (cc < A) Dg[cc * E + r] = ds[u];
+        }
+    }
+}
 template <int BLOCK>
 __device__ __forceinline__ void distance_pass(const KParams& p, const Lds& l, int G, int tid, bool only_reset) {
-    // One lane per UNORDERED entity pair (r < c) — agent-agent, agent-static and static-static alike — U independent
-    // pairs per trip (the pass is a chain of dependent LDS reads + an fp64 sqrt: latency-bound with one wave per SIMD).
+    // One lane per UNORDERED entity pair (r < c) — agent-agent, agent-static and static-static alike.
     // Pair index without a table: E even: w = a*(E-1)+b, a < E/2: b >= a -> (a, b+1), else the folded row (E-1-a, E-a+b);
     // E odd: w = a*((E-1)/2)+b -> (a, a+1+b mod E), the circulant enumeration. Each pair appears exactly once.
+    // A wave takes its remaining pairs (up to 5 per lane) in ONE interleaved trip, sized wave-uniformly so that no dead
+    // entry is computed (C2/C3 tile of 4 envs: 760 pairs on 256 lanes = 3 per lane).
     const int A = p.A, E = p.E, AE = A * E, EE4 = (E * E + 3) / 4 * 4;
     const int W = E * (E - 1) / 2;
     const bool even = (E & 1) == 0;
     const int dv = even ? E - 1 : (E - 1) / 2;
     const int total = G * W;
-    constexpr int U = 5;                                                // C2/C3 tile: 6 envs x 190 pairs = 1140 <= 5 x 256: one trip
-    for (int q0 = tid; q0 < total; q0 += U * BLOCK) {
-        double ds[U]; int gs[U], rs[U], cs[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int q = q0 + u * BLOCK;
-            const bool live = q < total;
-            const int qq = live ? q : 0;
-            const int g = fdiv(qq, W, p.m_W), w = qq - g * W;
-            const int a = fdiv(w, dv, p.m_Sx), b = w - a * dv;
-            int r, cc;
-            if (even) { const bool up = b >= a; r = up ? a : E - 1 - a; cc = up ? b + 1 : E - a + b; }
-            else { int c0 = a + 1 + b; c0 = c0 >= E ? c0 - E : c0; r = a < c0 ? a : c0; cc = a < c0 ? c0 : a; }
-            const double dx = l.ex[g * E + r] - l.ex[g * E + cc], dy = l.ey[g * E + r] - l.ey[g * E + cc];   // pos[min] - pos[max] (core.py:600-624)
-            ds[u] = (p.ablate & 16) ? dx * dx + dy * dy : sqrt(dx * dx + dy * dy);   // 16: timing diagnostic only
-            gs[u] = (live && !(only_reset && !l.flags[g * 4 + 0])) ? g : -1; rs[u] = r; cs[u] = cc;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (gs[u] < 0) continue;
-            const int r = rs[u], cc = cs[u];
-            float* Mg = l.M + (size_t)gs[u] * EE4;
-            const float df = (float)ds[u];
-            Mg[r * E + cc] = df; Mg[cc * E + r] = df;
-            if (r < A) {
-                double* Dg = l.Dm + (size_t)gs[u] * AE;
-                Dg[r * E + cc] = ds[u];
-                if (cc < A) Dg[cc * E + r] = ds[u];
-            }
-        }
+    const int wave_base = tid & ~63;
+    for (int base = 0; base + wave_base < total; base += 5 * BLOCK) {
+        const int left = total - (base + wave_base);                    // wave-uniform
+        const int nu = (left + BLOCK - 1) / BLOCK;
+        const int q0 = base + tid;
+        if (nu >= 5) distance_trip<BLOCK, 5>(p, l, q0, total, W, dv, even, only_reset);
+        else if (nu == 4) distance_trip<BLOCK, 4>(p, l, q0, total, W, dv, even, only_reset);
+        else if (nu == 3) distance_trip<BLOCK, 3>(p, l, q0, total, W, dv, even, only_reset);
+        else if (nu == 2) distance_trip<BLOCK, 2>(p, l, q0, total, W, dv, even, only_reset);
+        else distance_trip<BLOCK, 1>(p, l, q0, total, W, dv, even, only_reset);
     }
     for (int q = tid; q < G * E; q += BLOCK) {                           // diagonal
         const int g = fdiv(q, E, p.m_E), r = q - g * E;
