@@ -311,9 +311,9 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     const size_t stream_f4 = (size_t)G * h->A * ((size_t)E * E / 4 + 2 * (size_t)E);
     h->block = env_block ? atoi(env_block) : (block_sel ? block_sel : (stream_f4 <= 2048 ? 64 : (stream_f4 <= 6144 ? 128 : 256)));
     if (h->block != 64 && h->block != 128 && h->block != 256) h->block = 256;
-    // Specialisation pays while the per-agent arithmetic is comparable to the tile's store work (C2/C3: 36.7 -> 33.4 us);
-    // store-dominated tiles (C4/C5) want every wave on the stores (C4: 1337 us vs 1421 us specialised).
-    h->spec = getenv("GMPE_SPEC") ? atoi(getenv("GMPE_SPEC")) : (stream_f4 <= 16384 ? 1 : 0);
+    // Multi-wave tiles specialise (wave 0: reward / info / write-back, waves 1..: graph stores). Measured with the final register
+    // budgets: C2 30.2 vs 33.2 us, C4 1286 vs 1297 us, C5 shard 1901 vs 1970 us — on everywhere (GMPE_SPEC=0 turns it off).
+    h->spec = getenv("GMPE_SPEC") ? atoi(getenv("GMPE_SPEC")) : 1;
     const size_t lds = lds_bytes(h->G, h->A, E, h->D, cfg->num_walls);
     if (lds > 160 * 1024) { gmpe_destroy(h); return fail(GMPE_ERR_UNSUPPORTED, "per-tile LDS exceeds 160 KiB"); }
     if (lds > 48 * 1024) {                                   // opt in to >64 KiB dynamic LDS (gfx950: 160 KiB per CU)
