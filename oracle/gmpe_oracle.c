@@ -6,8 +6,9 @@
  *
  * Parity status: PINNED. tests/test_oracle_golden.py checks this file against vectors captured by
  * running the reference itself in the build container (tests/golden/make_fixtures.py):
- * end-to-end rollouts of MultiAgentGraphEnv on the July tube scenario incl. auto-resets and the
- * np.random draw order, scipy-RK45 single steps, and both force-path variants.
+ * end-to-end rollouts of MultiAgentGraphEnv on the July tube scenario and on the three shipped-weight
+ * scenarios (nav_graph_metered_single_corridor_rot_inv, two_phase_graph, three_phase_graph: 6 rollouts each)
+ * incl. auto-resets and the np.random draw order, scipy-RK45 single steps, and both force-path variants.
  * `navigation_graph` has no scenario file in the reference: its blocks are
  * pinned individually (force path, graph, obs slice, reward blocks) but their composition is this
  * project's own — "end-to-end parity unpinned" for that scenario.
