@@ -311,6 +311,40 @@ def test_full_size_properties_c3():
     eng.check_errors()
 
 
+@pytest.mark.parametrize("scen", ["navigation_graph"] + ROTFAM)
+def test_full_size_properties_other_scenarios(scen):
+    """4096 x 10 (the bench shapes c2 / c3r / c3p2 / c3p3): size-independent invariants + a 512-env slice against the oracle
+    (counter-based RNG keyed by global env id: envs [0, 512) of the big batch == a 512-env engine with the same seed)."""
+    import torch
+    cfg = gmpe.make_config(scenario_name=scen, num_envs=4096, num_agents=10, seed=1234, episode_length=25)
+    small = gmpe.make_config(scenario_name=scen, num_envs=512, num_agents=10, seed=1234, episode_length=25)
+    eng, orc = _engine(cfg), ol.Oracle(small)
+    eng.reset(); orc.reset()
+    g = torch.Generator(device="cpu"); g.manual_seed(43)
+    for t in range(30):
+        act = torch.randint(0, cfg.n_actions, (4096, 10), generator=g, dtype=torch.int32)
+        o = eng.step(act)
+        oo = orc.step(act[:512].numpy())
+    F = cfg.node_feats
+    adj = o.adj
+    assert torch.equal(adj, adj.transpose(-1, -2)) and (torch.diagonal(adj, dim1=-2, dim2=-1) == 0).all()
+    assert torch.equal(adj, adj[:, :1].expand_as(adj))
+    assert torch.isfinite(o.obs).all() and torch.isfinite(o.node_obs).all() and torch.isfinite(o.reward).all()
+    assert (o.node_obs[:, :, :10, F - 1] == 0).all() and (o.node_obs[:, :, 10:, F - 1] == 1).all()
+    idx = torch.arange(10, device=adj.device)
+    rel = o.node_obs[:, idx, :, 2:4].double()                    # rotation preserves the norm of rel_pos
+    d = torch.sqrt((rel ** 2).sum(-1)).float()
+    row = adj[:, idx, idx, :]
+    live = row != 0
+    assert torch.allclose(row[live], d[live], atol=2e-5)
+    np.testing.assert_allclose(_np(o.obs)[:512], oo[0], rtol=0, atol=TOL)
+    np.testing.assert_allclose(_np(o.node_obs)[:512], oo[2], rtol=0, atol=TOL)
+    np.testing.assert_allclose(_np(o.reward)[:512], oo[4], rtol=0, atol=TOL)
+    np.testing.assert_array_equal(_np(o.done)[:512].astype(bool), oo[5])
+    np.testing.assert_array_equal(eng.get("rng_ctr")[:512], orc.get("rng_ctr"))
+    eng.check_errors()
+
+
 # ---------------------------------------------------------------- other shapes / variants
 def test_c4_shape_obstacles_walls_vs_oracle():
     """BASELINE configs[3] shape: 32 agents + 8 obstacles + 4 walls (E = 72), small N."""
