@@ -357,6 +357,9 @@ int gmpe_destroy(gmpe_handle* h) {
 int gmpe_set_rng_tape(gmpe_handle* h, const double* tape_dev, int64_t len_per_env) {
     if (!h) return fail(GMPE_ERR_INVALID_ARG, "null handle");
     h->s.tape = tape_dev; h->s.tape_len = tape_dev ? len_per_env : 0;
+    // recorded rollouts bake the kernel parameters (tape pointer included) into their nodes: drop them
+    for (auto& g : h->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+    h->graphs.clear();
     return GMPE_OK;
 }
 

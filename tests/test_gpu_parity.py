@@ -438,6 +438,14 @@ def test_step_many_hipgraph_replay_equals_host_loop():
             assert torch.equal(getattr(o1, k), getattr(o2, k)), k
         _compare_state(e1, e2, "rep %d" % rep)
         acts.copy_(torch.randint(0, 25, (5, 70, 10), generator=g, device="cuda", dtype=torch.int32))
+    # a new RNG tape changes the kernel parameters: prepared graphs are dropped, the same call falls back to plain launches
+    tape = np.random.RandomState(3).rand(70, 4096)
+    e1.set_tape(tape); e2.set_tape(tape)
+    for k in range(12):
+        o1 = e1.step(acts[k % 5])
+    o2 = e2.step_many(acts, 12)
+    assert torch.equal(o1.obs, o2.obs) and torch.equal(o1.node_obs, o2.node_obs)
+    _compare_state(e1, e2, "after set_tape")
     o1 = [e1.step(acts[k % 5]) for k in range(7)][-1]
     o2 = e2.step_many(acts, 7)                            # not prepared -> plain launch loop
     assert torch.equal(o1.obs, o2.obs) and torch.equal(o1.adj, o2.adj)
