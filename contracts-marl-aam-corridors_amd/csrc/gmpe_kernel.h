@@ -566,6 +566,14 @@ template <int BLOCK, int AP, int SC>
 __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP > 0 && BLOCK > 64 ? 4 : GMPE_MIN_WAVES_NOWALLS))) void k_env(const KParams p) {
     constexpr bool WALLS = SC == SC_NAV_WALLS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    {   // Touch every 64-byte line of the 1.1 KB kernarg segment at once: the compiler fetches kernel parameters right before each
+        // use and waits for them one by one; after this batch those scalar loads hit the scalar cache.
+        const int __attribute__((address_space(4)))* ka = (const int __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+        int acc = 0;
+#pragma unroll
+        for (int q = 0; q < (int)((sizeof(KParams) + 63) / 64); ++q) acc ^= ka[q * 16];
+        asm volatile("" :: "s"(acc));
+    }
     const int tid = threadIdx.x;
     const int A = p.A, L = p.L, O = p.O, E = p.E, D = p.D, G = p.G, N = p.c.num_envs;
     const gmpe_config& c = p.c;
