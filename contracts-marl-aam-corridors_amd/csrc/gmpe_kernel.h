@@ -179,7 +179,7 @@ template <int AP, int SC>
 __device__ __forceinline__ void write_obs(const KParams& p, const Lds& l, int i, double vx, double vy, int phase) {
     float* o = l.obs + (size_t)i * p.D;
     const double px = l.ex[i], py = l.ey[i];
-    const double gx = l.ex[p.A + i] - px, gy = l.ey[p.A + i] - py;
+    const double gx = l.ex[(AP ? AP : p.A) + i] - px, gy = l.ey[(AP ? AP : p.A) + i] - py;
     o[0] = (float)px; o[1] = (float)py; o[2] = (float)vx; o[3] = (float)vy;
     o[4] = (float)gx; o[5] = (float)gy; o[6] = 0.0f; o[7] = (float)gx; o[8] = (float)gy;
     // stable two-smallest of the other agents (1398-1417): strict '<' keeps the first of equal distances
@@ -189,17 +189,17 @@ __device__ __forceinline__ void write_obs(const KParams& p, const Lds& l, int i,
     if (AP) {
         double rv[AP ? AP : 1];
 #pragma unroll
-        for (int k = 0; k < AP; ++k) rv[k] = row[k < p.A ? k : 0];
+        for (int k = 0; k < AP; ++k) rv[k] = row[k < (AP ? AP : p.A) ? k : 0];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < AP; ++k) {
-            const double d = (k < p.A && k != i) ? rv[k] : INF;
+            const double d = (k < (AP ? AP : p.A) && k != i) ? rv[k] : INF;
             const bool lt1 = d < d1, lt2 = d < d2;
             d2 = lt1 ? d1 : (lt2 ? d : d2); b2 = lt1 ? b1 : (lt2 ? k : b2);
             d1 = lt1 ? d : d1; b1 = lt1 ? k : b1;
         }
     } else {
-        for (int k = 0; k < p.A; ++k) {
+        for (int k = 0; k < (AP ? AP : p.A); ++k) {
             const double d = k != i ? row[k] : INF;
             const bool lt1 = d < d1, lt2 = d < d2;
             d2 = lt1 ? d1 : (lt2 ? d : d2); b2 = lt1 ? b1 : (lt2 ? k : b2);
@@ -419,7 +419,8 @@ __device__ __forceinline__ void distance_pass(const KParams& p, const Lds& l, in
 template <int BLOCK, int AP, int SC>
 __device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, const int Gv, const int n0, const int tid,
                                                 const int t0, const int nthr, const bool do_mask, const int any_mask) {
-    const int A = p.A, L = p.L, E = p.E, EE = E * E, EE4 = (EE + 3) / 4 * 4;
+    constexpr bool CT = AP > 0 && (SC == SC_NAV || SC == SC_JULY);
+    const int A = CT ? AP : p.A, L = CT ? AP : p.L, E = p.E, EE = E * E, EE4 = (EE + 3) / 4 * 4;
     const int abl = p.ablate;
     // ---- 6. adjacency mask (…_july.py:1627-1648): rows/cols of done agents and reached landmarks -> 0.
     // Only tiles that contain such an entity pay for this pass.
@@ -575,7 +576,10 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP >
         asm volatile("" :: "s"(acc));
     }
     const int tid = threadIdx.x;
-    const int A = p.A, L = p.L, O = p.O, E = p.E, D = p.D, G = p.G, N = p.c.num_envs;
+    // exact-size instantiations (the host selects AP only when A == L == AP) know A and L at compile time — in the two scenario
+    // variants where that does not cost registers (the rot_inv family spills under its 128-VGPR cap, the walls variant loses a wave)
+    constexpr bool CT = AP > 0 && (SC == SC_NAV || SC == SC_JULY);
+    const int A = CT ? AP : p.A, L = CT ? AP : p.L, O = p.O, E = p.E, D = p.D, G = p.G, N = p.c.num_envs;
     const gmpe_config& c = p.c;
     const Lds l = carve(smem, G, A, E, D, SC == SC_NAV_WALLS ? p.c.num_walls : 0);
     const int n0 = blockIdx.x * G;
