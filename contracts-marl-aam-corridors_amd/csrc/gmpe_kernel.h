@@ -41,7 +41,10 @@ struct KParams {
     unsigned long long* stamps;   // diagnostic build only (-DGMPE_STAMPS): [grid][16] s_memtime per phase
 };
 __host__ __device__ inline uint32_t magic_of(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(0x100000000ull / d) + 1u; }
-__device__ __forceinline__ int fdiv(int q, int d, uint32_t m) { return d <= 1 ? q : (int)__umulhi((uint32_t)q, m); }
+__device__ __forceinline__ int fdiv(int q, int d, uint32_t m) {
+    if (__builtin_constant_p(d)) return d <= 1 ? q : (int)((uint32_t)q / (uint32_t)d);   // exact-size instantiations: divisor known at compile time
+    return d <= 1 ? q : (int)__umulhi((uint32_t)q, m);
+}
 
 // ---------------------------------------------------------------- LDS carve (dynamic, 16-B aligned)
 // A workgroup owns G consecutive environments (G*A <= 64: every agent of every env is one lane of
@@ -420,7 +423,7 @@ template <int BLOCK, int AP, int SC>
 __device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, const int Gv, const int n0, const int tid,
                                                 const int t0, const int nthr, const bool do_mask, const int any_mask) {
     constexpr bool CT = AP > 0 && (SC == SC_NAV || SC == SC_JULY);
-    const int A = CT ? AP : p.A, L = CT ? AP : p.L, E = p.E, EE = E * E, EE4 = (EE + 3) / 4 * 4;
+    const int A = CT ? AP : p.A, L = CT ? AP : p.L, E = CT ? 2 * AP : p.E, EE = E * E, EE4 = (EE + 3) / 4 * 4;
     const int abl = p.ablate;
     // ---- 6. adjacency mask (…_july.py:1627-1648): rows/cols of done agents and reached landmarks -> 0.
     // Only tiles that contain such an entity pay for this pass.
@@ -578,8 +581,8 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP >
     const int tid = threadIdx.x;
     // exact-size instantiations (the host selects AP only when A == L == AP) know A and L at compile time — in the two scenario
     // variants where that does not cost registers (the rot_inv family spills under its 128-VGPR cap, the walls variant loses a wave)
-    constexpr bool CT = AP > 0 && (SC == SC_NAV || SC == SC_JULY);
-    const int A = CT ? AP : p.A, L = CT ? AP : p.L, O = p.O, E = p.E, D = p.D, G = p.G, N = p.c.num_envs;
+    constexpr bool CT = AP > 0 && (SC == SC_NAV || SC == SC_JULY);     // host: AP > 0 only if A == L == AP and O == 0
+    const int A = CT ? AP : p.A, L = CT ? AP : p.L, O = CT ? 0 : p.O, E = CT ? 2 * AP : p.E, D = CT ? (SC == SC_JULY ? 19 : 13) : p.D, G = p.G, N = p.c.num_envs;
     const gmpe_config& c = p.c;
     const Lds l = carve(smem, G, A, E, D, SC == SC_NAV_WALLS ? p.c.num_walls : 0);
     const int n0 = blockIdx.x * G;

@@ -274,7 +274,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) dev_cus = prop.multiProcessorCount; }
     int Gmax = 64 / h->A; if (Gmax < 1) Gmax = 1; if (Gmax > (int)N) Gmax = (int)N;
     while (Gmax > 1 && lds_bytes(Gmax, h->A, E, h->D, cfg->num_walls) > 48 * 1024) --Gmax;
-    const int ap_sel = (h->A == h->L && (h->A == 10 || h->A == 3)) ? h->A : 0;
+    const int ap_sel = (h->A == h->L && h->O == 0 && (h->A == 10 || h->A == 3)) ? h->A : 0;
     int G = 0, block_sel = 0;
     if (!env_g && !env_block) {
         int G0 = (int)((N + 4 * (size_t)dev_cus - 1) / (4 * (size_t)dev_cus));
@@ -417,7 +417,7 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
         e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1];
         HIPCHK(hipEventRecord(e0, st));
     }
-    const int ap = (h->A == h->L && (h->A == 10 || h->A == 3)) ? h->A : 0;   // exact-size instantiations of the common cases
+    const int ap = (h->A == h->L && h->O == 0 && (h->A == 10 || h->A == 3)) ? h->A : 0;   // exact-size instantiations of the common cases (A = L, no obstacles)
     switch (sc_of(h->c)) {
         case SC_NAV: launch_env<SC_NAV>(h->block, ap, grid, lds, st, p); break;
         case SC_NAV_WALLS: launch_env<SC_NAV_WALLS>(h->block, ap, grid, lds, st, p); break;
