@@ -180,7 +180,7 @@ __device__ __forceinline__ void decode_action(const gmpe_config& c, int idx, dou
 // the first get_agent_phase call of the step. Uses the PRE-reward own velocity (vox/voy).
 template <int AP, int SC>
 __device__ __forceinline__ void write_obs(const KParams& p, const Lds& l, int i, double vx, double vy, int phase) {
-    float* o = l.obs + (size_t)i * p.D;
+    float* o = l.obs + (size_t)i * ((AP > 0 && (SC == SC_NAV || SC == SC_JULY)) ? (SC == SC_JULY ? 19 : 13) : p.D);
     const double px = l.ex[i], py = l.ey[i];
     const double gx = l.ex[(AP ? AP : p.A) + i] - px, gy = l.ey[(AP ? AP : p.A) + i] - py;
     o[0] = (float)px; o[1] = (float)py; o[2] = (float)vx; o[3] = (float)vy;
@@ -188,7 +188,7 @@ __device__ __forceinline__ void write_obs(const KParams& p, const Lds& l, int i,
     // stable two-smallest of the other agents (1398-1417): strict '<' keeps the first of equal distances
     const double INF = __builtin_huge_val();
     int b1 = -1, b2 = -1; double d1 = INF, d2 = INF;
-    const double* row = l.Dm + (size_t)i * p.E;
+    const double* row = l.Dm + (size_t)i * ((AP > 0 && (SC == SC_NAV || SC == SC_JULY)) ? 2 * AP : p.E);
     if (AP) {
         double rv[AP ? AP : 1];
 #pragma unroll
@@ -353,9 +353,9 @@ __device__ __forceinline__ void reset_world_serial(const KParams& p, const Lds& 
 // delta taken as pos[min]-pos[max], so the matrix is exactly symmetric). Writes the fp64 agent rows
 // Dm[g][r][c] (r < A) AND the whole unmasked fp32 matrix M, static (landmark / obstacle) block included.
 // U independent pairs of one lane (q0, q0+BLOCK, ...), interleaved: the pass is a chain of dependent LDS reads + an fp64 sqrt
-template <int BLOCK, int U>
+template <int BLOCK, int U, int CA>
 __device__ __forceinline__ void distance_trip(const KParams& p, const Lds& l, int q0, int total, int W, int dv, bool even, bool only_reset) {
-    const int A = p.A, E = p.E, AE = A * E, EE4 = (E * E + 3) / 4 * 4;
+    const int A = CA ? CA : p.A, E = CA ? 2 * CA : p.E, AE = A * E, EE4 = (E * E + 3) / 4 * 4;
     double ds[U]; int gs[U], rs[U], cs[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -385,14 +385,14 @@ __device__ __forceinline__ void distance_trip(const KParams& p, const Lds& l, in
         }
     }
 }
-template <int BLOCK>
+template <int BLOCK, int CA>
 __device__ __forceinline__ void distance_pass(const KParams& p, const Lds& l, int G, int tid, bool only_reset) {
     // One lane per UNORDERED entity pair (r < c) — agent-agent, agent-static and static-static alike.
     // Pair index without a table: E even: w = a*(E-1)+b, a < E/2: b >= a -> (a, b+1), else the folded row (E-1-a, E-a+b);
     // E odd: w = a*((E-1)/2)+b -> (a, a+1+b mod E), the circulant enumeration. Each pair appears exactly once.
     // A wave takes its remaining pairs (up to 5 per lane) in ONE interleaved trip, sized wave-uniformly so that no dead
     // entry is computed (C2/C3 tile of 4 envs: 760 pairs on 256 lanes = 3 per lane).
-    const int A = p.A, E = p.E, AE = A * E, EE4 = (E * E + 3) / 4 * 4;
+    const int A = CA ? CA : p.A, E = CA ? 2 * CA : p.E, AE = A * E, EE4 = (E * E + 3) / 4 * 4;
     const int W = E * (E - 1) / 2;
     const bool even = (E & 1) == 0;
     const int dv = even ? E - 1 : (E - 1) / 2;
@@ -402,11 +402,11 @@ __device__ __forceinline__ void distance_pass(const KParams& p, const Lds& l, in
         const int left = total - (base + wave_base);                    // wave-uniform
         const int nu = (left + BLOCK - 1) / BLOCK;
         const int q0 = base + tid;
-        if (nu >= 5) distance_trip<BLOCK, 5>(p, l, q0, total, W, dv, even, only_reset);
-        else if (nu == 4) distance_trip<BLOCK, 4>(p, l, q0, total, W, dv, even, only_reset);
-        else if (nu == 3) distance_trip<BLOCK, 3>(p, l, q0, total, W, dv, even, only_reset);
-        else if (nu == 2) distance_trip<BLOCK, 2>(p, l, q0, total, W, dv, even, only_reset);
-        else distance_trip<BLOCK, 1>(p, l, q0, total, W, dv, even, only_reset);
+        if (nu >= 5) distance_trip<BLOCK, 5, CA>(p, l, q0, total, W, dv, even, only_reset);
+        else if (nu == 4) distance_trip<BLOCK, 4, CA>(p, l, q0, total, W, dv, even, only_reset);
+        else if (nu == 3) distance_trip<BLOCK, 3, CA>(p, l, q0, total, W, dv, even, only_reset);
+        else if (nu == 2) distance_trip<BLOCK, 2, CA>(p, l, q0, total, W, dv, even, only_reset);
+        else distance_trip<BLOCK, 1, CA>(p, l, q0, total, W, dv, even, only_reset);
     }
     for (int q = tid; q < G * E; q += BLOCK) {                           // diagonal
         const int g = fdiv(q, E, p.m_E), r = q - g * E;
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP >
         }
         __syncthreads();
         STAMP(3);
-        distance_pass<BLOCK>(p, l, Gv, tid, false);                    // post-move rows: obs, reward, info, adj all read these
+        distance_pass<BLOCK, (CT ? AP : 0)>(p, l, Gv, tid, false);                    // post-move rows: obs, reward, info, adj all read these
         __syncthreads();
         STAMP(4);
 
@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP >
                 ph1 = ph;
             }
             __syncthreads();                                                // positions of all agents final
-            distance_pass<BLOCK>(p, l, Gv, tid, true);
+            distance_pass<BLOCK, (CT ? AP : 0)>(p, l, Gv, tid, true);
             __syncthreads();
             if (mine) { if (rotfam) write_obs_rot<AP, SC>(p, v, i, ph1); else write_obs<AP, SC>(p, v, i, v.vox[i], v.voy[i], ph1); }
             any_mask = 0;
