@@ -419,12 +419,13 @@ __device__ __forceinline__ void distance_pass(const KParams& p, const Lds& l, in
 #define SWEEP(var, n) _Pragma("unroll") for (int var = 0; var < (AP ? AP : (n)); ++var)
 // Graph outputs of a tile: optional adjacency mask pass (block-wide, with its barrier), then the adj and node_obs
 // stores executed by threads t0, t0+nthr, ... (all BLOCK threads, or only the streaming waves of a specialised tile).
-template <int BLOCK, int AP, int SC>
+template <int BLOCK, int AP, int SC, int FL>
 __device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, const int Gv, const int n0, const int tid,
                                                 const int t0, const int nthr, const bool do_mask, const int any_mask) {
     constexpr bool CT = AP > 0 && (SC == SC_NAV || SC == SC_JULY);
     const int A = CT ? AP : p.A, L = CT ? AP : p.L, E = CT ? 2 * AP : p.E, EE = E * E, EE4 = (EE + 3) / 4 * 4;
-    const int abl = p.ablate;
+    const int abl = FL ? 0 : p.ablate;
+    const bool nt = FL ? false : p.nt != 0;                              // FL: the steady-state instantiation (step, no ablation, ordinary stores)
     // ---- 6. adjacency mask (…_july.py:1627-1648): rows/cols of done agents and reached landmarks -> 0.
     // Only tiles that contain such an entity pay for this pass.
     if (do_mask && any_mask && !(abl & 4)) {
@@ -460,7 +461,7 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, 
                     if (!l.flags[gg * 4 + 3]) continue;
                     const float4 val = reinterpret_cast<const float4*>(l.M + (size_t)gg * EE4)[m];
                     float4* d4 = reinterpret_cast<float4*>(dst) + (size_t)gg * A * nq + m;
-                    SWEEP(a, A) { if (!AP || a < A) { if (p.nt) nt_store4(&d4[(size_t)a * nq], val); else d4[(size_t)a * nq] = val; } }
+                    SWEEP(a, A) { if (!AP || a < A) { if (nt) nt_store4(&d4[(size_t)a * nq], val); else d4[(size_t)a * nq] = val; } }
                 }
             } else {
                 const int AEE = A * EE;
@@ -542,7 +543,7 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, 
                 } else {
                     val = make_float4((float)(gx - px), (float)(gy - py), occ, typ);
                 }
-                if (ok) { if (p.nt) nt_store4(&dst[(size_t)ec * E2], val); else dst[(size_t)ec * E2] = val; }
+                if (ok) { if (nt) nt_store4(&dst[(size_t)ec * E2], val); else dst[(size_t)ec * E2] = val; }
             }
         }
     }
@@ -566,7 +567,9 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, 
 // Out-of-range iterations read a clamped index and are masked in the arithmetic. AP == 0: run-time bounds.
 // SC: scenario variant (above). Only SC_NAV_WALLS compiles the wall-contact code (asin / cos / softplus inside the agent lane's dynamics) out: it is
 // the single largest consumer of registers (187 -> 135 VGPRs), i.e. 2 -> 3 waves per SIMD for wall-less worlds.
-template <int BLOCK, int AP, int SC>
+// FL = 1: the steady-state instantiation — step mode, wave specialisation on, ordinary stores, no ablation — with those run-time
+// flags folded (selected by the host when they hold; everything else takes FL = 0).
+template <int BLOCK, int AP, int SC, int FL>
 __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP > 0 && BLOCK > 64 ? 4 : GMPE_MIN_WAVES_NOWALLS))) void k_env(const KParams p) {
     constexpr bool WALLS = SC == SC_NAV_WALLS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP >
     const int Gv = min(G, N - n0);                                      // envs actually present in this tile
     constexpr bool july = SC == SC_JULY, rotinv = SC == SC_ROT, rotfam = sc_rotfam(SC), two = SC == SC_TWO, three = SC == SC_THREE;
     constexpr int PV = two ? 1 : (three ? 2 : 0);                        // phase FSM variant (gmpe_device.h)
-    const bool step = p.mode == MODE_STEP;
+    const bool step = FL ? true : p.mode == MODE_STEP;
     constexpr bool kin = sc_kinematic(SC);
     const int EE = E * E, EE4 = (EE + 3) / 4 * 4, AD4 = (A * D + 3) / 4 * 4;
     const double INF = __builtin_huge_val();
@@ -705,7 +708,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP >
             // the 14-pair tail costs one wave, not four). Branch-free: nearly every wave holds a pair inside the softplus
             // range; far pairs get pen = log1p(exp(-large)) = 0 like in the reference.
             for (int q = tid; q < Gv * W; q += BLOCK) {
-                if (p.ablate & 8) { Fx[q] = 0.0; Fy[q] = 0.0; continue; }   // timing diagnostic only (wrong results)
+                if (!FL && (p.ablate & 8)) { Fx[q] = 0.0; Fy[q] = 0.0; continue; }   // timing diagnostic only (wrong results)
                 const int gg = fdiv(q, W, p.m_FW), w = q - gg * W;
                 const bool apair = w < NP;
                 const int pk = l.ptab[apair ? w : 0];
@@ -862,7 +865,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP >
 
     int any_reset = 0, any_mask = 0;
     for (int gg = 0; gg < Gv; ++gg) { any_reset |= l.flags[gg * 4 + 0]; any_mask |= l.flags[gg * 4 + 2]; }   // block-uniform
-    const int abl = p.ablate;
+    const int abl = FL ? 0 : p.ablate;
 
 
     // Common case (no env of the tile resets): issue the 22 KB/env of graph stores FIRST, then do the reward /
@@ -871,8 +874,8 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP >
     const bool early = step && !any_reset;
     // Multi-wave tiles specialise: wave 0 (all agent lanes) does reward / info / write-back while waves 1.. stream the
     // graph observations, so the ~7 us of per-agent arithmetic runs beside the store issue instead of after it.
-    const bool spec = early && BLOCK > 64 && p.spec;
-    if (early && !spec) stream_graph_fn<BLOCK, AP, SC>(p, l, Gv, n0, tid, tid, BLOCK, true, any_mask);
+    const bool spec = early && BLOCK > 64 && (FL ? true : p.spec != 0);
+    if (early && !spec) stream_graph_fn<BLOCK, AP, SC, FL>(p, l, Gv, n0, tid, tid, BLOCK, true, any_mask);
     if (spec) {
         if (any_mask && !(abl & 4)) {
             for (int q = tid; q < Gv * EE; q += BLOCK) {
@@ -1128,7 +1131,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP >
                 if (p.o.agent_id) for (int q = tid; q < Gv * A; q += 64) { const int gg = fdiv(q, A, p.m_A); if (l.flags[gg * 4 + 3]) p.o.agent_id[(size_t)n0 * A + q] = q - gg * A; }
             }
         }
-        else stream_graph_fn<BLOCK, AP, SC>(p, l, Gv, n0, tid, tid - 64, BLOCK - 64, false, any_mask);
+        else stream_graph_fn<BLOCK, AP, SC, FL>(p, l, Gv, n0, tid, tid - 64, BLOCK - 64, false, any_mask);
         __syncthreads();
     }
     {
@@ -1173,7 +1176,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP >
         }
         STAMP(8);
     }
-    if (!early) stream_graph_fn<BLOCK, AP, SC>(p, l, Gv, n0, tid, tid, BLOCK, true, any_mask);
+    if (!early) stream_graph_fn<BLOCK, AP, SC, FL>(p, l, Gv, n0, tid, tid, BLOCK, true, any_mask);
     // ---- small outputs: obs staging rows and agent ids. In a specialised tile wave 0 has already stored them
     // (it wrote the staging rows itself), so nobody waits behind the barrier for the streaming waves.
     STAMP(11);
@@ -1191,8 +1194,8 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP >
 
 
 // Host entry points of one scenario variant; defined and explicitly instantiated in gmpe_sc.hip (-DGMPE_SC=k).
-template <int SC> void launch_env(int block, int ap, dim3 grid, size_t lds, hipStream_t st, const KParams& p);
+template <int SC> void launch_env(int block, int ap, int fl, dim3 grid, size_t lds, hipStream_t st, const KParams& p);
 template <int SC> hipError_t set_max_lds(int lds);
-template <int SC> int max_tiles_per_cu(int block, int ap, size_t lds);
+template <int SC> int max_tiles_per_cu(int block, int ap, size_t lds);   // of the steady-state (FL) instantiation where one exists
 
 }  // namespace gmpe

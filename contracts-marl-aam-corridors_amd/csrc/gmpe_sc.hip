@@ -9,11 +9,12 @@
 namespace gmpe {
 
 template <int SC>
-void launch_env(int block, int ap, dim3 grid, size_t lds, hipStream_t st, const KParams& p) {
+void launch_env(int block, int ap, int fl, dim3 grid, size_t lds, hipStream_t st, const KParams& p) {
+    if (fl && block == 256 && ap == 10) { hipLaunchKernelGGL((k_env<256, 10, SC, 1>), grid, dim3(256), lds, st, p); return; }
 #define LAUNCH_ENV(B) do { \
-        if (ap == 10) hipLaunchKernelGGL((k_env<B, 10, SC>), grid, dim3(B), lds, st, p); \
-        else if (ap == 3) hipLaunchKernelGGL((k_env<B, 3, SC>), grid, dim3(B), lds, st, p); \
-        else hipLaunchKernelGGL((k_env<B, 0, SC>), grid, dim3(B), lds, st, p); \
+        if (ap == 10) hipLaunchKernelGGL((k_env<B, 10, SC, 0>), grid, dim3(B), lds, st, p); \
+        else if (ap == 3) hipLaunchKernelGGL((k_env<B, 3, SC, 0>), grid, dim3(B), lds, st, p); \
+        else hipLaunchKernelGGL((k_env<B, 0, SC, 0>), grid, dim3(B), lds, st, p); \
     } while (0)
     switch (block) {
         case 64: LAUNCH_ENV(64); break;
@@ -26,20 +27,21 @@ void launch_env(int block, int ap, dim3 grid, size_t lds, hipStream_t st, const 
 // opt in to > 64 KiB of dynamic LDS (gfx950: 160 KiB per CU)
 template <int SC>
 hipError_t set_max_lds(int lds) {
-#define FN(B, P) reinterpret_cast<const void*>(&k_env<B, P, SC>)
-    const void* fns[9] = {FN(64, 0), FN(64, 3), FN(64, 10), FN(128, 0), FN(128, 3), FN(128, 10), FN(256, 0), FN(256, 3), FN(256, 10)};
+#define FN(B, P) reinterpret_cast<const void*>(&k_env<B, P, SC, 0>)
+    const void* fns[10] = {FN(64, 0), FN(64, 3), FN(64, 10), FN(128, 0), FN(128, 3), FN(128, 10), FN(256, 0), FN(256, 3), FN(256, 10),
+                           reinterpret_cast<const void*>(&k_env<256, 10, SC, 1>)};
 #undef FN
     hipError_t e = hipSuccess;
-    for (int q = 0; q < 9 && e == hipSuccess; ++q) e = hipFuncSetAttribute(fns[q], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    for (int q = 0; q < 10 && e == hipSuccess; ++q) e = hipFuncSetAttribute(fns[q], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     return e;
 }
 
 // resident workgroups per CU of the instantiation launch_env would pick (registers + LDS), 0 on error
 template <int SC>
 int max_tiles_per_cu(int block, int ap, size_t lds) {
-#define FN(B, P) reinterpret_cast<const void*>(&k_env<B, P, SC>)
+#define FN(B, P) reinterpret_cast<const void*>(&k_env<B, P, SC, 0>)
 #define PICK(B) (ap == 10 ? FN(B, 10) : (ap == 3 ? FN(B, 3) : FN(B, 0)))
-    const void* fn = block == 64 ? PICK(64) : (block == 128 ? PICK(128) : PICK(256));
+    const void* fn = block == 64 ? PICK(64) : (block == 128 ? PICK(128) : (ap == 10 ? reinterpret_cast<const void*>(&k_env<256, 10, SC, 1>) : PICK(256)));
 #undef PICK
 #undef FN
     int nb = 0;
@@ -47,7 +49,7 @@ int max_tiles_per_cu(int block, int ap, size_t lds) {
     return nb;
 }
 
-template void launch_env<GMPE_SC>(int, int, dim3, size_t, hipStream_t, const KParams&);
+template void launch_env<GMPE_SC>(int, int, int, dim3, size_t, hipStream_t, const KParams&);
 template int max_tiles_per_cu<GMPE_SC>(int, int, size_t);
 template hipError_t set_max_lds<GMPE_SC>(int);
 

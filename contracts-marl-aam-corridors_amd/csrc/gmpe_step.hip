@@ -418,13 +418,14 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
         HIPCHK(hipEventRecord(e0, st));
     }
     const int ap = (h->A == h->L && h->O == 0 && (h->A == 10 || h->A == 3)) ? h->A : 0;   // exact-size instantiations of the common cases (A = L, no obstacles)
+    const int fl = (mode == MODE_STEP && !h->nt && !h->ablate && h->spec) ? 1 : 0;   // steady-state instantiation (flags folded)
     switch (sc_of(h->c)) {
-        case SC_NAV: launch_env<SC_NAV>(h->block, ap, grid, lds, st, p); break;
-        case SC_NAV_WALLS: launch_env<SC_NAV_WALLS>(h->block, ap, grid, lds, st, p); break;
-        case SC_JULY: launch_env<SC_JULY>(h->block, ap, grid, lds, st, p); break;
-        case SC_ROT: launch_env<SC_ROT>(h->block, ap, grid, lds, st, p); break;
-        case SC_TWO: launch_env<SC_TWO>(h->block, ap, grid, lds, st, p); break;
-        default: launch_env<SC_THREE>(h->block, ap, grid, lds, st, p); break;
+        case SC_NAV: launch_env<SC_NAV>(h->block, ap, fl, grid, lds, st, p); break;
+        case SC_NAV_WALLS: launch_env<SC_NAV_WALLS>(h->block, ap, fl, grid, lds, st, p); break;
+        case SC_JULY: launch_env<SC_JULY>(h->block, ap, fl, grid, lds, st, p); break;
+        case SC_ROT: launch_env<SC_ROT>(h->block, ap, fl, grid, lds, st, p); break;
+        case SC_TWO: launch_env<SC_TWO>(h->block, ap, fl, grid, lds, st, p); break;
+        default: launch_env<SC_THREE>(h->block, ap, fl, grid, lds, st, p); break;
     }
     HIPCHK(hipGetLastError());
     if (h->timing && !h->capturing) { HIPCHK(hipEventRecord(e1, st)); h->ev_used += 2; }
