@@ -422,7 +422,7 @@ __device__ __forceinline__ void distance_pass(const KParams& p, const Lds& l, in
 template <int BLOCK, int AP, int SC, int FL>
 __device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, const int Gv, const int n0, const int tid,
                                                 const int t0, const int nthr, const bool do_mask, const int any_mask) {
-    constexpr bool CT = AP > 0 && (SC == SC_NAV || SC == SC_JULY);
+    constexpr bool CT = AP > 0 && SC != SC_NAV_WALLS;
     const int A = CT ? AP : p.A, L = CT ? AP : p.L, E = CT ? 2 * AP : p.E, EE = E * E, EE4 = (EE + 3) / 4 * 4;
     const int abl = FL ? 0 : p.ablate;
     const bool nt = FL ? false : p.nt != 0;                              // FL: the steady-state instantiation (step, no ablation, ordinary stores)
@@ -570,7 +570,7 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, 
 // FL = 1: the steady-state instantiation — step mode, wave specialisation on, ordinary stores, no ablation — with those run-time
 // flags folded (selected by the host when they hold; everything else takes FL = 0).
 template <int BLOCK, int AP, int SC, int FL>
-__global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP > 0 && BLOCK > 64 ? 4 : GMPE_MIN_WAVES_NOWALLS))) void k_env(const KParams p) {
+__global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP > 0 && BLOCK > 64 ? (sc_rotfam(SC) ? 3 : 4) : GMPE_MIN_WAVES_NOWALLS))) void k_env(const KParams p) {
     constexpr bool WALLS = SC == SC_NAV_WALLS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     {   // Touch every 64-byte line of the 1.1 KB kernarg segment at once: the compiler fetches kernel parameters right before each
@@ -582,10 +582,11 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP >
         asm volatile("" :: "s"(acc));
     }
     const int tid = threadIdx.x;
-    // exact-size instantiations (the host selects AP only when A == L == AP) know A and L at compile time — in the two scenario
-    // variants where that does not cost registers (the rot_inv family spills under its 128-VGPR cap, the walls variant loses a wave)
-    constexpr bool CT = AP > 0 && (SC == SC_NAV || SC == SC_JULY);     // host: AP > 0 only if A == L == AP and O == 0
-    const int A = CT ? AP : p.A, L = CT ? AP : p.L, O = CT ? 0 : p.O, E = CT ? 2 * AP : p.E, D = CT ? (SC == SC_JULY ? 19 : 13) : p.D, G = p.G, N = p.c.num_envs;
+    // exact-size instantiations (the host selects AP only when A == L == AP, O == 0) know A, L, E, D at compile time. The rot_inv
+    // family needs ~130-150 VGPRs for that and is compiled for 3 waves per SIMD (the tile-shape search then packs 6 envs per tile);
+    // the walls variant would lose a wave and keeps run-time sizes.
+    constexpr bool CT = AP > 0 && SC != SC_NAV_WALLS;     // host: AP > 0 only if A == L == AP and O == 0
+    const int A = CT ? AP : p.A, L = CT ? AP : p.L, O = CT ? 0 : p.O, E = CT ? 2 * AP : p.E, D = CT ? (SC == SC_JULY ? 19 : (sc_phasefam(SC) ? 15 : 13)) : p.D, G = p.G, N = p.c.num_envs;
     const gmpe_config& c = p.c;
     const Lds l = carve(smem, G, A, E, D, SC == SC_NAV_WALLS ? p.c.num_walls : 0);
     const int n0 = blockIdx.x * G;
