@@ -1,5 +1,6 @@
 // gmpe_sc.hip — one scenario variant of the fused kernel per translation unit (compiled with -DGMPE_SC=<variant>, in
-// parallel): tile shapes BLOCK in {64,128,256} x exact-size instantiations AP in {0,3,10}.
+// parallel): tile shapes BLOCK in {64,128,256} x exact-size instantiations AP in {0,3,10}, plus the steady-state instantiation
+// <256, 10, SC, FL = 1> (run-time flags folded) that the C2/C3-shaped workloads run.
 #include "gmpe_kernel.h"
 
 #ifndef GMPE_SC

@@ -1,19 +1,19 @@
-// gmpe_step.hip — fused GraphMPE step / reset kernel for gfx950 (MI355X) + the C ABI of include/gmpe.h.
+// gmpe_step.hip — host side of libgmpe.so: the C ABI of include/gmpe.h, state allocation, tile-shape selection, launches,
+// hipGraph replay of open-loop rollouts, timing hooks, and the three small edge-compaction kernels (process_adj).
 //
-// One workgroup per environment. Everything the reference does for one env in one
-// `MultiAgentGraphEnv.step` (multiagent/environment.py:1021-1063) + the worker's auto-reset
+// The fused GraphMPE step / reset kernel lives in gmpe_kernel.h (template k_env<BLOCK, AP, SC, FL>) and is instantiated per
+// scenario variant by gmpe_sc.hip. A workgroup (tile) owns G consecutive environments; everything the reference does for one
+// env in one `MultiAgentGraphEnv.step` (multiagent/environment.py:1021-1063) + the worker's auto-reset
 // (onpolicy/envs/env_wrappers.py:865-870) happens inside ONE launch:
 //
-//   load SoA state -> LDS | decode action + integrate (closed-form unicycle, or MPE soft-contact
-//   forces) | phase FSM + goal reach (parallel restatement of the sequential agent loop, SURVEY.md
-//   §8a "ordered-visibility rule") | reward / done / info | optional reset (serial rejection sampler
-//   on lane 0) | E×E distance matrix in LDS | coalesced 16-byte stores of adj [A,E,E], node_obs
-//   [A,E,8], obs [A,D].
+//   load SoA state -> LDS | decode action + integrate (closed-form unicycle, or MPE soft-contact forces, pair-parallel) |
+//   all-pairs distances | phase FSM + goal reach (parallel restatement of the sequential agent loop, SURVEY.md §8a
+//   "ordered-visibility rule") | graph stores (adj [A,E,E], node_obs [A,E,F]: 16-byte coalesced) by waves 1.. while wave 0
+//   does reward / done / info / write-back | optional reset (serial rejection sampler on one lane per env).
 //
-// HBM-bound by construction: per env-step the kernel reads ~1 KB of state and writes
-// 4·A·(E² + 8E + D + 2) bytes of fp32 observations; no MFMA (there is no contraction here).
-// All geometry is fp64 with contraction OFF so thresholds see the reference's roundings; values are
-// rounded to fp32 once, on store, like GraphReplayBuffer's float32 copy (graph_buffer.py:226).
+// HBM-bound by construction: per env-step the kernel reads ~1 KB of state and writes 4·A·(E² + F·E + D + 2) bytes of fp32
+// observations; no MFMA (there is no contraction here). All geometry is fp64 with contraction OFF so thresholds see the
+// reference's roundings; values are rounded to fp32 once, on store, like GraphReplayBuffer's float32 copy (graph_buffer.py:226).
 #include "gmpe_kernel.h"
 
 namespace gmpe {
