@@ -83,6 +83,19 @@ __global__ __launch_bounds__(256) void k_edge_write(const float* __restrict__ ad
     }
 }
 
+// GraphReplayBuffer.insert's mask rules (onpolicy/utils/graph_buffer.py:223-251, graph_mpe_runner.py:85-90, 395-405) from the step's
+// dones: masks = 0 where done; active_masks = 0 where done unless every agent of the env is done. One thread per (env, agent).
+__global__ __launch_bounds__(256) void k_masks(const uint8_t* __restrict__ done, int N, int A, float* __restrict__ masks, float* __restrict__ active) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= N * A) return;
+    const int n = q / A;
+    bool all = true;
+    for (int a = 0; a < A; ++a) all = all && done[(size_t)n * A + a] != 0;
+    const bool d = done[q] != 0;
+    if (masks) masks[q] = d ? 0.0f : 1.0f;
+    if (active) active[q] = (d && !all) ? 0.0f : 1.0f;
+}
+
 }  // namespace gmpe
 
 // =================================================================== host side / C ABI
@@ -524,6 +537,14 @@ int gmpe_edges_from_adj(gmpe_handle* h, const float* adj_dev, int32_t batch, int
     return GMPE_OK;
 }
 
+int gmpe_masks_from_dones(gmpe_handle* h, const uint8_t* done_dev, float* masks_dev, float* active_masks_dev, void* stream) {
+    if (!h || !done_dev) return fail(GMPE_ERR_INVALID_ARG, "gmpe_masks_from_dones: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    const int total = h->c.num_envs * h->A;
+    hipLaunchKernelGGL(k_masks, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), done_dev, h->c.num_envs, h->A, masks_dev, active_masks_dev);
+    HIPCHK(hipGetLastError());
+    return GMPE_OK;
+}
 int gmpe_timing_mark(gmpe_handle* h, int32_t which, void* stream) {
     if (!h || which < 0 || which > 1) return fail(GMPE_ERR_INVALID_ARG, "gmpe_timing_mark: bad arguments");
     HIPCHK(hipSetDevice(h->device));

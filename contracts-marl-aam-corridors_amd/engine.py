@@ -184,6 +184,12 @@ class GmpeEngine(object):
         m = int(ne.item())
         return ei[:, :min(m, cap)], ea[:min(m, cap)], m
 
+    def masks_from_dones(self, done, masks, active_masks):
+        """masks / active_masks (f32 [N,A,...], contiguous, N*A elements) from a uint8 [N,A] done tensor, one tiny kernel."""
+        _lib.check(self.lib.gmpe_masks_from_dones(self.h, done.data_ptr(), masks.data_ptr() if masks is not None else None,
+                                                  active_masks.data_ptr() if active_masks is not None else None, self._stream()),
+                   "gmpe_masks_from_dones")
+
     # ------------------------------------------------------------------ timing hooks
     def timing(self, enable):
         _lib.check(self.lib.gmpe_timing_enable(self.h, int(bool(enable))), "gmpe_timing_enable")

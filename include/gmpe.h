@@ -226,6 +226,11 @@ int gmpe_edges_from_adj(gmpe_handle* h, const float* adj_dev, int32_t batch, int
                         float max_edge_dist, int32_t inclusive, int32_t* edge_index_dev,
                         float* edge_attr_dev, int32_t cap, int32_t* n_edges_dev, void* stream);
 
+/* Rollout-buffer masks from a step's dones (GraphReplayBuffer.insert: onpolicy/utils/graph_buffer.py:223-251 with the runner's
+ * rules graph_mpe_runner.py:85-90, 395-405): masks f32 [N,A] = 0 where done; active_masks f32 [N,A] = 0 where done unless all agents of
+ * the env are done. Either output may be NULL. */
+int gmpe_masks_from_dones(gmpe_handle* h, const uint8_t* done_dev, float* masks_dev, float* active_masks_dev, void* stream);
+
 /* Timing hooks used by bench.py: HIP events on the handle's launch stream around every step
  * kernel, so the dominant kernel's duration is measured live (not via torch's current stream). */
 int gmpe_timing_enable(gmpe_handle* h, int32_t enable);          /* one event pair around EVERY launch (perturbs back-to-back launches by ~5 us each) */
