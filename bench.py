@@ -7,8 +7,15 @@
 
 A "step" is one pass of the hot path (decode action -> integrate -> distances -> reward/done/info ->
 auto-reset -> graph observation) over one batch of 4096 environments per GPU, synthetic uniform
-random actions already resident in HBM. One process per GPU; env ranges are sharded across ranks
-with NO communication inside step, so scaling is weak (4096 envs per GPU).
+random actions already resident in HBM, outputs written to HBM. One process per GPU; env ranges are
+sharded across ranks with NO communication inside step, so scaling is weak (4096 envs
+per GPU).
+
+The timed region is EXACTLY K steps, repeated `--reps` times (default 5); `value` is the
+MEDIAN repetition (max over ranks of each). By default the K steps of a repetition are one launch of the
+persistent rollout kernel (gmpe_step_many -> gmpe_rollout_steps: open-loop rollout, state carried in LDS);
+`--host-loop` / `--launch-loop` time the closed-loop shape (one launch per step) instead, and the default
+line carries that number too (`closed_loop`).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
 """
@@ -48,6 +55,10 @@ WORKLOADS = {
                world_size=12.0, episode_length=25, envs=16384),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+HEADLINE_METRIC = "env-steps/sec (whole node) at 4096 envs x 10 agents, navigation_graph"     # BASELINE.json `metric` (configs[1] = c2)
+# Knobs that change which kernel instantiation / library runs. Performance knobs are recorded; result-changing ones are refused.
+PERF_KNOBS = ("GMPE_G", "GMPE_BLOCK", "GMPE_NT", "GMPE_SPEC", "GMPE_SPLIT", "GMPE_ROLL", "GMPE_GROLL")
+DIAG_KNOBS = ("GMPE_ABLATE", "GMPE_LIB")
 
 
 def cpu_baseline(wl, budget_s=12.0):
@@ -76,25 +87,64 @@ def cpu_baseline(wl, budget_s=12.0):
                       "(oracle/gmpe_oracle.c, fp64 outputs)" % (n, steps, el)}
 
 
+def numpy_boundary(wl, n_envs, device, steps=12):
+    """PCIe-inclusive rate of the drop-in boundary the unchanged runner uses (never `value`): BatchedGraphMPEVecEnv.step with the
+    runner's float one-hot actions [N,A,n_act] in NumPy and NumPy observations out (graph_mpe_runner.py:343-382)."""
+    import argparse as ap
+    import numpy as np
+    from gmpe.vec_env import BatchedGraphMPEVecEnv
+    a = ap.Namespace(env_name="GraphMPE", scenario_name=wl["scenario_name"], dynamics_type=None, world_size=wl["world_size"],
+                     num_agents=wl["num_agents"], num_landmarks=wl["num_agents"], num_scripted_agents=0, num_obstacles=wl["num_obstacles"],
+                     num_walls=wl["num_walls"], collaborative=False, max_speed=2, collision_rew=5, formation_rew=1, goal_rew=5,
+                     episode_length=wl["episode_length"], n_rollout_threads=n_envs, total_actions=5, graph_feat_type="relative",
+                     discrete_action=True, use_safety_filter=False, seed=1234)
+    env = BatchedGraphMPEVecEnv(a, num_envs=n_envs, device=device)
+    env.reset()
+    rng = np.random.RandomState(0)
+    n_act = env.action_space[0].n
+    onehot = np.eye(n_act, dtype=np.float32)[rng.randint(0, n_act, (4, n_envs, wl["num_agents"]))]
+    for k in range(3):
+        env.step(onehot[k % 4])
+    t0 = time.perf_counter()
+    for k in range(steps):
+        env.step(onehot[k % 4])
+    el = time.perf_counter() - t0
+    env.close()
+    return {"value": n_envs * steps / el, "unit": "env-steps/s", "ms_per_step": el / steps * 1e3, "steps": steps,
+            "what": "BatchedGraphMPEVecEnv.step: float32 one-hot NumPy actions in (pinned H2D), NumPy obs / node_obs / adj (zero-copy "
+                    "broadcast of the compact matrix) / reward / done out (pinned D2H); PCIe-inclusive, never `value`"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step timed region; the median is reported (SURVEY 8d)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: workload's)")
     ap.add_argument("--adj-compact", action="store_true", help="write one ExE matrix per env instead of A copies")
     ap.add_argument("--no-info", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-loop", action="store_true", help="call gmpe_step from Python once per step instead of gmpe_step_many")
-    ap.add_argument("--no-graph", action="store_true", help="plain launch loop inside gmpe_step_many instead of the prepared hipGraph")
-    ap.add_argument("--gather", action="store_true", help="also time step + RCCL all_gather of the compact rollout slab")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the NumPy-boundary (PCIe-inclusive) side measurement")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip the one-launch-per-step side measurement")
+    ap.add_argument("--host-loop", action="store_true", help="timed region = gmpe_step called from Python once per step (closed-loop shape)")
+    ap.add_argument("--launch-loop", action="store_true", help="timed region = one launch per step enqueued by one C call (hipGraph of K kernel nodes)")
+    ap.add_argument("--slots", type=int, default=1, help="rollout output slots: 1 = every step overwrites the same buffers; T = slot-per-step storage [T, ...]")
+    ap.add_argument("--gather", action="store_true", help="also time step + RCCL gather of the compact rollout slab to rank 0")
+    ap.add_argument("--diag", action="store_true", help="allow GMPE_LIB / GMPE_ABLATE (diagnostic A/B runs; recorded in the line, never a result)")
     args = ap.parse_args()
+
+    env_knobs = {k: os.environ[k] for k in PERF_KNOBS + DIAG_KNOBS if k in os.environ}
+    bad = [k for k in DIAG_KNOBS if k in env_knobs]
+    if bad and not args.diag:
+        sys.exit("bench.py: %s set — these select a diagnostic library / wrong-by-construction ablations; unset them or pass --diag" % ", ".join(bad))
 
     import numpy as np
     import torch
     import gmpe
-    from gmpe.engine import GmpeEngine
+    from gmpe.config import algorithmic_bytes_per_env_step
+    from gmpe.engine import GmpeEngine, StepOutputs
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -122,12 +172,16 @@ def main():
     weak = args.workload in ("c2", "c3", "c3r", "c3p2", "c3p3")             # 4096 envs PER GPU; c4/c5 split a fixed total
     n_envs = args.envs or (wl["envs"] if weak else wl["envs"] // world)
     # configs[1]/[2] are quoted per GPU (4096 envs on 1 MI355X): weak scaling keeps 4096 per GPU
-    cfg = gmpe.make_config(scenario_name=wl["scenario_name"], num_envs=n_envs, num_agents=wl["num_agents"],
-                           num_obstacles=wl["num_obstacles"], num_walls=wl["num_walls"],
-                           world_size=wl["world_size"], episode_length=wl["episode_length"],
-                           seed=1234, env_id_base=rank * n_envs)
+    mk = lambda: gmpe.make_config(scenario_name=wl["scenario_name"], num_envs=n_envs, num_agents=wl["num_agents"],
+                                  num_obstacles=wl["num_obstacles"], num_walls=wl["num_walls"],
+                                  world_size=wl["world_size"], episode_length=wl["episode_length"],
+                                  seed=1234, env_id_base=rank * n_envs)
+    cfg = mk()
     eng = GmpeEngine(cfg, device=local_rank, adj_compact=args.adj_compact, with_info=not args.no_info)
-    K, W = args.steps, args.warmup
+    tuning = eng.tuning()
+    if tuning["diag_build"] and not args.diag:
+        sys.exit("bench.py: libgmpe.so is a -DGMPE_DIAG build (ablations compiled in); rebuild with `make` or pass --diag")
+    K, W, R = args.steps, args.warmup, max(1, args.reps)
     g = torch.Generator(device=dev); g.manual_seed(42 + rank)
     # synthetic uniform random actions for every step, generated on device and resident in HBM
     n_act_sets = min(K + W, 256)
@@ -135,108 +189,184 @@ def main():
     eng.reset()
     for k in range(W):
         eng.step(actions[k % n_act_sets])
+
+    # ---- what one repetition of the timed region launches
+    rollout_ok = bool(tuning["roll"]) and not tuning["split"] and not tuning["nt"]
+    mode = "host-loop" if args.host_loop else ("launch-loop" if (args.launch_loop or not rollout_ok) else "rollout")
+    slots = None
+    if mode == "rollout" and args.slots > 1:
+        T = args.slots                                   # slot-per-step storage, as DeviceRolloutBuffer keeps it
+        o = eng.out
+        keys = [k for k in StepOutputs.__slots__ if getattr(o, k) is not None]
+        slots = {k: torch.empty((T,) + tuple(getattr(o, k).shape), dtype=getattr(o, k).dtype, device=dev) for k in keys}
     graph_ok = False
-    if not args.host_loop and not args.no_graph:
+    if mode == "launch-loop":
         try:
-            eng.step_many_prepare(actions, K)    # capture + instantiate the K-launch hipGraph: setup, outside the timed region
+            eng.step_many_prepare(actions, K)            # capture + instantiate the K-launch hipGraph: setup, outside the timed region
             graph_ok = True
-        except Exception as e:                   # same kernels either way: without a graph gmpe_step_many loops over plain launches
+        except Exception as e:                           # same kernels either way: without a graph gmpe_step_many loops over plain launches
             print("bench.py: hipGraph capture unavailable (%s); using the launch loop" % e, file=sys.stderr)
-    torch.cuda.synchronize(dev)
+
+    def run_k_steps(kk):
+        if mode == "host-loop":
+            for k in range(kk):
+                eng.step(actions[(W + k) % n_act_sets])
+        elif mode == "rollout" and slots is not None:
+            eng.rollout(actions, kk, slot0=StepOutputs(**{k: v[0] for k, v in slots.items()}), num_slots=args.slots,
+                        strides={k: v[0].numel() for k, v in slots.items()})
+        elif mode == "rollout":
+            eng.rollout(actions, kk)                     # ONE launch: the persistent rollout kernel
+        else:
+            eng.step_many_loop(actions, kk)              # one C call, one launch per step (prepared hipGraph when available)
+    # rollout: ONE launch covers the K steps; otherwise one k_env launch per step (+ k_adj_expand on the split path: priced together)
+    launches_per_rep = 1 if mode == "rollout" else K
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    # ---- timed region: EXACTLY K steps. One HIP event pair on the LAUNCH stream brackets the K launches
-    # (recorded by libgmpe.so itself): average launch duration = elapsed / K. Per-launch event pairs are not
-    # used here because they perturb back-to-back launches (~+5 us per step, measured); they are taken in a
-    # separate short pass below for comparison with the rocprofv3 per-kernel average.
-    barrier(); torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    eng.region_mark(0)
-    if args.host_loop:
-        for k in range(K):
-            eng.step(actions[(W + k) % n_act_sets])
-    else:
-        # one C call enqueues the K launches (gmpe_step_many): no Python / ctypes round trip between steps
-        eng.step_many(actions, K)
-    eng.region_mark(1)
-    torch.cuda.synchronize(dev); barrier()
-    t1 = time.perf_counter()
-    region_ms = eng.region_ms()
-    kern_ms, launches = region_ms, K
-    # separate pass: per-launch events (isolated kernel duration incl. event overhead)
-    eng.timing(True); eng.timing_read(reset=True)
-    eng.step_many(actions, min(K, 200))
-    torch.cuda.synchronize(dev)
-    iso_ms, iso_n = eng.timing_read(reset=True)
-    eng.timing(False)
-    eng.check_errors()
-    el = t1 - t0
     red_dev = dev if (dist is not None and dist.get_backend() == "nccl") else torch.device("cpu")
-    if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+
+    def timed(fn, kk):
+        """barrier + sync | HIP event on the launch stream | fn | event | sync + barrier  ->  (wall s max over ranks, event ms)"""
+        barrier(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        eng.region_mark(0)
+        fn(kk)
+        eng.region_mark(1)
+        torch.cuda.synchronize(dev); barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, eng.region_ms()
+
+    run_k_steps(min(K, 50)); torch.cuda.synchronize(dev)            # untimed: first use of this launch shape
+    reps = [timed(run_k_steps, K) for _ in range(R)]
+    eng.check_errors()
+    order = sorted(range(R), key=lambda q: reps[q][0])
+    med = order[(R - 1) // 2]                                        # the median repetition (lower median for even R)
+    el, region_ms = reps[med]
+
+    # ---- side measurement: the closed-loop shape (one launch per step, what a policy-in-the-loop runner gets per step)
+    closed = None
+    if mode == "rollout" and not args.no_closed_loop:
+        kc = min(K, 300)
+        try:
+            eng.step_many_prepare(actions, kc)
+        except Exception:
+            pass
+        eng.step_many_loop(actions, kc); torch.cuda.synchronize(dev)
+        cl = [timed(lambda kk: eng.step_many_loop(actions, kk), kc) for _ in range(3)]
+        cl_el, cl_ms = sorted(cl)[1]
+        closed = {"ms_per_step": cl_ms / kc, "steps": kc, "launches": kc,
+                  "what": "one k_env launch per step (hipGraph of K kernel nodes), same buffers: launch + latency chain + drain per step"}
+    # separate pass: per-launch events (isolated kernel duration incl. event overhead)
+    iso = None
+    if mode != "rollout" or not args.no_closed_loop:
+        eng.timing(True); eng.timing_read(reset=True)
+        eng.step_many_loop(actions, min(K, 200))
+        torch.cuda.synchronize(dev)
+        iso_ms, iso_n = eng.timing_read(reset=True)
+        eng.timing(False)
+        iso = iso_ms / max(1, iso_n)
+    eng.check_errors()
 
     gather = None
     if args.gather and dist is not None:
         from gmpe.sharding import RolloutGather
-        rg = RolloutGather(eng, world)
+        eng_c = eng if args.adj_compact else GmpeEngine(mk(), device=local_rank, adj_compact=True, with_info=not args.no_info)
+        eng_c.reset()
+        rg = RolloutGather(eng_c, world, dst=0, mode="gather")
         for k in range(5):
             rg.step_and_gather(actions[k % n_act_sets])
+        kg = min(K, 200)
         barrier(); torch.cuda.synchronize(dev)
         tg0 = time.perf_counter()
-        for k in range(K):
-            rg.step_and_gather(actions[(W + k) % n_act_sets])
+        last = None
+        for k in range(kg):                                         # depth-2 pipeline: gather of step k overlaps step k+1
+            last = rg.step_and_gather_async(actions[(W + k) % n_act_sets])
+        rg.wait(last); rg.wait(last ^ 1)
         torch.cuda.synchronize(dev); barrier()
         tg = torch.tensor([time.perf_counter() - tg0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-        gather = {"value": world * n_envs * K / float(tg.item()), "unit": "env-steps/s",
-                  "what": "step + RCCL all_gather of the compact rollout slab (obs, node_obs, ExE adj, reward, done)"}
+        gather = {"value": world * n_envs * kg / float(tg.item()), "unit": "env-steps/s", "steps": kg, "slab_bytes_per_rank": rg.slab_bytes,
+                  "what": "closed-loop step (one launch) + RCCL gather of the compact rollout slab (obs, node_obs, ExE adj, reward, done) "
+                          "to rank 0, gather of step k overlapped with step k+1"}
 
     if rank == 0:
-        B = eng.bytes_per_env_step                      # SURVEY.md §8(d) algorithmic bytes per env-step
-        avg_ms = kern_ms / max(1, launches)
-        achieved = B * n_envs / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        pj = os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % args.workload)
-        if os.path.exists(pj):
-            try:
-                traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        fill = None                                    # what a pure streaming-store kernel reaches on this part (tools_fillbw.hip)
+        B = algorithmic_bytes_per_env_step(cfg, adj_compact=args.adj_compact)      # SURVEY.md §8(d), for the outputs this run really writes
+        env_steps_per_launch = n_envs * K // launches_per_rep
+        avg_ms = region_ms / launches_per_rep
+        achieved = B * env_steps_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic, traffic_src = None, None
+        for tag in ("r02", "r01"):
+            pj = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (tag, args.workload))
+            if os.path.exists(pj) and traffic is None:
+                try:
+                    d = json.load(open(pj))
+                    traffic = d.get("hbm_bytes_per_env_step", d.get("hbm_bytes_per_launch", 0) / max(1, d.get("env_steps_per_launch", wl["envs"]))) * env_steps_per_launch
+                    traffic_src = "profiles/%s_pmc_%s.json: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE in separate runs of this command (NOT measured in this run), scaled to this launch's env-steps" % (tag, args.workload)
+                except Exception:
+                    traffic = None
+        fill = None                                    # what a pure streaming-store kernel reaches on this part (tools/fillbw.hip)
         fj = os.path.join(ROOT, "profiles", "r01_fillbw.json")
         if os.path.exists(fj):
             try:
                 fill = json.load(open(fj))["fill_GBps"]["98MB" if B * n_envs < (512 << 20) else "6GB"]
             except Exception:
                 fill = None
+        kernel = {"rollout": "gmpe::k_env<BLOCK, 0, SC, 2> (persistent rollout: K steps per launch)",
+                  "launch-loop": "gmpe::k_env (one launch per step)" + (" + gmpe::k_adj_expand" if tuning["split"] and not args.adj_compact else ""),
+                  "host-loop": "gmpe::k_env (one launch per step, Python loop)"}[mode]
+        restated = wl["scenario_name"] == "navigation_graph"
         out = {
-            "metric": "env-steps/sec (whole node) at 4096 envs x 10 agents, navigation_graph",
+            "metric": HEADLINE_METRIC if args.workload == "c2" and n_envs == 4096 else "env-steps/sec (whole node), " + wl["name"],
             "value": world * n_envs * K / el, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wl["name"], "key": args.workload, "envs_per_gpu": n_envs,
-                       "agents": cfg.num_agents, "entities": cfg.num_entities, "obs_dim": cfg.obs_dim,
+            "repetitions": {"n": R, "reported": "median", "env_steps_per_s": [world * n_envs * K / r[0] for r in reps],
+                            "region_ms": [r[1] for r in reps]},
+            "config": {"workload": wl["name"] + (" [scenario restated from the reference's blocks: end-to-end parity unpinned, DESIGN.md §6]" if restated else ""),
+                       "key": args.workload, "envs_per_gpu": n_envs,
+                       "agents": cfg.num_agents, "entities": cfg.num_entities, "obs_dim": cfg.obs_dim, "node_feats": cfg.node_feats,
                        "episode_length": cfg.episode_length, "adj": "compact [N,E,E]" if args.adj_compact else "materialised [N,A,E,E]",
-                       "info": not args.no_info,
-                       "launch": "host loop" if args.host_loop else ("hipGraph of K kernel nodes (gmpe_step_many_prepare)" if graph_ok else "launch loop in gmpe_step_many"),
+                       "info": not args.no_info, "state_dtype": "f64", "outputs_dtype": "f32 / i32 / u8",
+                       "launch": {"rollout": "ONE launch of the persistent rollout kernel for the K steps (gmpe_rollout_steps), outputs: "
+                                             + ("%d slots [T, ...]" % args.slots if slots is not None else "one slot (every step overwrites the same buffers)"),
+                                  "launch-loop": "one launch per step from one C call" + (" (hipGraph of K kernel nodes)" if graph_ok else ""),
+                                  "host-loop": "one launch per step, Python loop over gmpe_step"}[mode],
+                       "tuning": tuning, "env": env_knobs, "diag": bool(args.diag),
                        "sharding": "env ranges, %d per GPU, no collective in step" % n_envs},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "measured_fill_peak": fill, "frac_of_measured_fill": (achieved / fill) if fill else None,
-                         "kernel": "gmpe::k_env", "avg_launch_ms": avg_ms, "launches": launches,
-                         "timing": "one HIP event pair on the launch stream around the K launches of the timed region",
-                         "isolated_launch_ms": iso_ms / max(1, iso_n),
-                         "algorithmic_bytes_per_env_step": B, "env_steps_per_launch": n_envs},
+                         "kernel": kernel, "avg_launch_ms": avg_ms, "launches": launches_per_rep,
+                         "timing": "one HIP event pair on the launch stream around the launch(es) of the median repetition",
+                         "isolated_launch_ms": iso,
+                         "algorithmic_bytes_per_env_step": B, "env_steps_per_launch": env_steps_per_launch},
         }
+        if closed is not None:
+            closed["frac"] = B * n_envs / (closed["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            closed["env_steps_per_s"] = n_envs / (closed["ms_per_step"] * 1e-3)
+            out["closed_loop"] = closed
         if gather is not None:
             out["with_gather"] = gather
+        if world == 1 and not args.no_boundary:
+            try:
+                out["numpy_boundary"] = numpy_boundary(wl, n_envs, local_rank)
+            except Exception as e:                      # a side measurement never takes the line down
+                out["numpy_boundary"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl)
+            cb = cpu_baseline(wl)
+            cj = os.path.join(ROOT, "profiles", "r02_cpu_calibration.json")
+            if os.path.exists(cj):
+                try:
+                    cb["calibration"] = json.load(open(cj))
+                except Exception:
+                    pass
+            out["cpu_baseline"] = cb
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -5,20 +5,36 @@ import os
 from .config import GmpeConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GMPE_LIB: diagnostic override to A/B another build of the SAME library (tools_*.py); never a fallback
+# GMPE_LIB: diagnostic override to A/B another build of the SAME library (tools/*.py); never a fallback. bench.py refuses to report
+# a number with it set (unless --diag, which records it in the JSON line).
 LIB_PATH = os.environ.get("GMPE_LIB") or os.path.join(_HERE, "libgmpe.so")
 _lib = None
 
 SYMBOLS = ["gmpe_abi_version", "gmpe_last_error", "gmpe_obs_dim", "gmpe_node_feats", "gmpe_num_entities", "gmpe_create",
            "gmpe_destroy", "gmpe_set_rng_tape", "gmpe_reset", "gmpe_step", "gmpe_step_many", "gmpe_step_many_prepare", "gmpe_step_onehot",
            "gmpe_field_bytes", "gmpe_get_field", "gmpe_set_field", "gmpe_edges_from_adj", "gmpe_masks_from_dones",
-           "gmpe_timing_enable", "gmpe_timing_read", "gmpe_timing_mark", "gmpe_timing_region_ms"]
+           "gmpe_timing_enable", "gmpe_timing_read", "gmpe_timing_mark", "gmpe_timing_region_ms",
+           "gmpe_rollout_steps", "gmpe_get_tuning", "gmpe_step_many_launches"]
 
 
 class GmpeOutputs(C.Structure):
     _fields_ = [("obs", C.c_void_p), ("agent_id", C.c_void_p), ("node_obs", C.c_void_p),
                 ("adj", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),
                 ("info", C.c_void_p), ("adj_compact", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GmpeRollout(C.Structure):
+    """gmpe_rollout (include/gmpe.h): K steps in one launch, step k -> output slot (first_slot + k) % num_slots."""
+    _fields_ = [("num_steps", C.c_int32), ("num_action_sets", C.c_int32), ("num_slots", C.c_int32), ("first_slot", C.c_int32),
+                ("stride_obs", C.c_int64), ("stride_agent_id", C.c_int64), ("stride_node_obs", C.c_int64), ("stride_adj", C.c_int64),
+                ("stride_reward", C.c_int64), ("stride_done", C.c_int64), ("stride_info", C.c_int64), ("stride_masks", C.c_int64),
+                ("masks", C.c_void_p), ("active_masks", C.c_void_p)]
+
+
+class GmpeTuning(C.Structure):
+    _fields_ = [("G", C.c_int32), ("block", C.c_int32), ("nt", C.c_int32), ("spec", C.c_int32), ("split", C.c_int32),
+                ("roll", C.c_int32), ("ap", C.c_int32), ("lds_bytes", C.c_int32), ("diag_build", C.c_int32),
+                ("G_roll", C.c_int32), ("block_roll", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class GmpeError(RuntimeError):
@@ -48,6 +64,7 @@ def load():
     lib.gmpe_step.argtypes = [P, P, C.POINTER(GmpeOutputs), P]
     lib.gmpe_step_onehot.argtypes = [P, P, C.POINTER(GmpeOutputs), P]
     lib.gmpe_step_many.argtypes = [P, P, C.c_int32, C.c_int32, C.POINTER(GmpeOutputs), P]
+    lib.gmpe_step_many_launches.argtypes = [P, P, C.c_int32, C.c_int32, C.POINTER(GmpeOutputs), P]
     lib.gmpe_step_many_prepare.argtypes = [P, P, C.c_int32, C.c_int32, C.POINTER(GmpeOutputs)]
     lib.gmpe_field_bytes.argtypes = [P, I, C.POINTER(C.c_size_t)]
     lib.gmpe_get_field.argtypes = [P, I, P, C.c_size_t]
@@ -58,7 +75,10 @@ def load():
     lib.gmpe_timing_read.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]
     lib.gmpe_timing_mark.argtypes = [P, C.c_int32, P]
     lib.gmpe_timing_region_ms.argtypes = [P, C.POINTER(C.c_double)]
-    if lib.gmpe_abi_version() != 1:
+    lib.gmpe_rollout_steps.argtypes = [P, P, C.POINTER(GmpeRollout), C.POINTER(GmpeOutputs), P]
+    lib.gmpe_get_tuning.argtypes = [P, C.POINTER(GmpeTuning)]
+    from .config import ABI_VERSION
+    if lib.gmpe_abi_version() != ABI_VERSION:
         raise GmpeError("libgmpe.so ABI version mismatch")
     _lib = lib
     return lib

@@ -9,7 +9,7 @@ import math
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NODE_FEATS = 8
 INFO_KEYS = ["individual_reward", "Dist_to_goal", "Time_req_to_goal", "Num_agent_collisions",
              "Num_obst_collisions", "Distance_mean", "Distance_variance", "Mean_by_variance",
@@ -227,7 +227,10 @@ for _i, (_name, _dt, _shape) in enumerate([
     FIELDS[_name] = (_i, np.dtype(_dt), _shape)
 
 
-def algorithmic_bytes_per_env_step(cfg):
-    """B = 4*A*(E^2 + E*F + D + 2) + A + 4*A + 2*A*S, S = 48 B/agent."""
+def algorithmic_bytes_per_env_step(cfg, adj_compact=False):
+    """B = 4*A*(E^2 + E*F + D + 2) + A + 4*A + 2*A*S, S = 48 B/agent. With the compact adjacency the engine
+    writes ONE E x E matrix per env instead of A copies, and only that is counted. (The optional `info` output, 72 B/agent, is
+    never counted.)"""
     A, E, F, D = cfg.num_agents, cfg.num_entities, cfg.node_feats, cfg.obs_dim
-    return 4 * A * (E * E + E * F + D + 2) + A + 4 * A + 2 * A * 48
+    adj = E * E if adj_compact else A * E * E
+    return 4 * (adj + A * (E * F + D + 2)) + A + 4 * A + 2 * A * 48

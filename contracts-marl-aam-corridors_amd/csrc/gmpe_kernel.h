@@ -35,7 +35,13 @@ struct KParams {
     int G;                    // envs per workgroup (G*A <= 64)
     int spec;                 // 1: multi-wave tiles specialise (wave 0 reward/info, waves 1.. graph stores)
     int nt;                   // 1: nontemporal graph stores (outputs per launch exceed the 256 MiB Infinity Cache)
-    int ablate;               // debug: timing-only builds of the kernel skip parts (GMPE_ABLATE)
+    int ablate;               // diagnostic build only (-DGMPE_DIAG): timing-only ablations; the shipped library ignores it
+    // rollout (FL == 2 instantiations, gmpe_rollout_steps): K steps inside one launch, state carried in LDS / registers
+    int K, S;                 // steps, action sets (step k reads action set k % S of act [S,N,A])
+    int num_slots, first_slot;   // outputs of step k go to slot (first_slot + k) % num_slots
+    long long st_obs, st_id, st_node, st_adj, st_rew, st_done, st_info, st_mask;   // slot strides in elements
+    float* masks;             // optional [slots][N,A] GraphReplayBuffer masks / active_masks of the step (graph_buffer.py:223-251)
+    float* active;
     // magic multipliers for exact unsigned division by run-time constants (q < 2^22): floor(q/d) = umulhi(q, m)
     uint32_t m_E, m_AE, m_EE, m_nq, m_2E, m_pe, m_AD, m_A, m_L, m_O, m_C, m_AC, m_AEE, m_W, m_Sx, m_FW;
     unsigned long long* stamps;   // diagnostic build only (-DGMPE_STAMPS): [grid][16] s_memtime per phase
@@ -45,6 +51,13 @@ __device__ __forceinline__ int fdiv(int q, int d, uint32_t m) {
     if (__builtin_constant_p(d)) return d <= 1 ? q : (int)((uint32_t)q / (uint32_t)d);   // exact-size instantiations: divisor known at compile time
     return d <= 1 ? q : (int)__umulhi((uint32_t)q, m);
 }
+
+// Timing-only ablations (wrong results by construction) exist in the diagnostic build alone: -DGMPE_DIAG (Makefile target `diag`).
+#ifdef GMPE_DIAG
+#define GMPE_ABL(p) ((p).ablate)
+#else
+#define GMPE_ABL(p) 0
+#endif
 
 // ---------------------------------------------------------------- LDS carve (dynamic, 16-B aligned)
 // A workgroup owns G consecutive environments (G*A <= 64: every agent of every env is one lane of
@@ -61,7 +74,7 @@ struct Lds {
     double *tube;                     // [G][12]
     double *Dm;                       // [G][A][E] fp64 agent->entity distances (rows of cached_dist_mag)
     double *fw;                       // [G][A][2*NW] wall contact forces (x, y per wall), walls variant only
-    double *cntd;                     // [G][A][2] goal_min_time, prev_proj + [G] delta_spacing: staged by the loader lanes
+    double *cntd;                     // [G][A][2] goal_min_time, prev_proj + [G] delta_spacing: staged by the loader lanes; + [G] int64 RNG counter after a reset (rollouts)
     int *s_old, *newf, *gt;           // [G][A]  status before, newly-reached flag, goal_tracker (final)
     int *dtg_o, *dtg_n, *trq_o, *trq_n, *sv_o, *sv_n;   // [G][A] info counters old/new
     int *flags;                       // [G][4]  0: reset this env, 1: heading draws this step, 2: env has masked nodes, 3: env active
@@ -73,7 +86,7 @@ struct Lds {
 };
 __host__ __device__ inline size_t lds_bytes(int G, int A, int E, int D, int NW) {
     const size_t EE4 = ((size_t)E * E + 3) / 4 * 4, AD4 = ((size_t)A * D + 3) / 4 * 4;
-    size_t d = (size_t)G * (2 * E + 14 * A + 13 + (size_t)A * E + (size_t)A * 2 * NW);   // doubles
+    size_t d = (size_t)G * (2 * E + 14 * A + 14 + (size_t)A * E + (size_t)A * 2 * NW);   // doubles
     size_t f = (size_t)G * (EE4 + AD4);                             // floats
     size_t i = (size_t)G * (18 * A + 4 + E) + (size_t)A * (A - 1) / 2 + 1;   // ints
     return d * 8 + 16 + f * 4 + ((i * 4 + 15) / 16) * 16 + 32;
@@ -87,7 +100,7 @@ __device__ inline Lds carve(char* base, int G, int A, int E, int D, int NW) {
     l.serr = d; d += G * A; l.cn = d; d += G * A; l.sn = d; d += G * A; l.rew = d; d += G * A; l.tube = d; d += G * 12;
     l.Dm = d; d += (size_t)G * A * E;
     l.fw = d; d += (size_t)G * A * 2 * NW;
-    l.cntd = d; d += (size_t)G * (2 * A + 1);
+    l.cntd = d; d += (size_t)G * (2 * A + 2);
     if ((uintptr_t)d & 15) d += 1;
     float* f = reinterpret_cast<float*>(d);
     const size_t EE4 = ((size_t)E * E + 3) / 4 * 4, AD4 = ((size_t)A * D + 3) / 4 * 4;
@@ -368,7 +381,7 @@ __device__ __forceinline__ void distance_trip(const KParams& p, const Lds& l, in
         if (even) { const bool up = b >= a; r = up ? a : E - 1 - a; cc = up ? b + 1 : E - a + b; }
         else { int c0 = a + 1 + b; c0 = c0 >= E ? c0 - E : c0; r = a < c0 ? a : c0; cc = a < c0 ? c0 : a; }
         const double dx = l.ex[g * E + r] - l.ex[g * E + cc], dy = l.ey[g * E + r] - l.ey[g * E + cc];   // pos[min] - pos[max] (core.py:600-624)
-        ds[u] = (p.ablate & 16) ? dx * dx + dy * dy : sqrt(dx * dx + dy * dy);   // 16: timing diagnostic only
+        ds[u] = (GMPE_ABL(p) & 16) ? dx * dx + dy * dy : sqrt(dx * dx + dy * dy);   // 16: diagnostic build only
         gs[u] = (live && !(only_reset && !l.flags[g * 4 + 0])) ? g : -1; rs[u] = r; cs[u] = cc;
     }
 #pragma unroll
@@ -420,11 +433,11 @@ __device__ __forceinline__ void distance_pass(const KParams& p, const Lds& l, in
 // Graph outputs of a tile: optional adjacency mask pass (block-wide, with its barrier), then the adj and node_obs
 // stores executed by threads t0, t0+nthr, ... (all BLOCK threads, or only the streaming waves of a specialised tile).
 template <int BLOCK, int AP, int SC, int FL>
-__device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, const int Gv, const int n0, const int tid,
+__device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_outputs& o, const Lds& l, const int Gv, const int n0, const int tid,
                                                 const int t0, const int nthr, const bool do_mask, const int any_mask) {
     constexpr bool CT = AP > 0 && SC != SC_NAV_WALLS;
     const int A = CT ? AP : p.A, L = CT ? AP : p.L, E = CT ? 2 * AP : p.E, EE = E * E, EE4 = (EE + 3) / 4 * 4;
-    const int abl = FL ? 0 : p.ablate;
+    const int abl = FL ? 0 : GMPE_ABL(p);
     const bool nt = FL ? false : p.nt != 0;                              // FL: the steady-state instantiation (step, no ablation, ordinary stores)
     // ---- 6. adjacency mask (…_july.py:1627-1648): rows/cols of done agents and reached landmarks -> 0.
     // Only tiles that contain such an entity pay for this pass.
@@ -440,10 +453,10 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, 
     
 
     // ---- 7. stream the observations out (16-byte stores wherever the row length allows)
-    if (p.o.adj && !(abl & 1)) {
+    if (o.adj && !(abl & 1)) {
         const bool vec = (EE & 3) == 0;
-        if (p.o.adj_compact) {
-            float* dst = p.o.adj + (size_t)n0 * EE;
+        if (o.adj_compact) {
+            float* dst = o.adj + (size_t)n0 * EE;
             if (vec) {
                 const int nq = EE / 4;
                 for (int q = t0; q < Gv * nq; q += nthr) {
@@ -452,7 +465,7 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, 
                 }
             } else for (int q = t0; q < Gv * EE; q += nthr) { const int gg = fdiv(q, EE, p.m_EE); if (l.flags[gg * 4 + 3]) dst[q] = l.M[(size_t)gg * EE4 + (q - gg * EE)]; }
         } else {
-            float* dst = p.o.adj + (size_t)n0 * A * EE;
+            float* dst = o.adj + (size_t)n0 * A * EE;
             if (vec) {
                 const int nq = EE / 4;
                 // each lane keeps one float4 of the env's matrix and stores it to the A ego copies
@@ -473,11 +486,11 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, 
         }
     }
     
-    if (sc_rotfam(SC) && p.o.node_obs && !(abl & 2)) {
+    if (sc_rotfam(SC) && o.node_obs && !(abl & 2)) {
         // rot_inv node row (…rot_inv.py:1690-1766): 7 float32 = [rel_vel, rel_pos, rel_goal (all rotated by the ego heading), type].
         // Positions / velocities are rounded to float32 FIRST, differenced in float32, rotated in float64, rounded again.
         // A lane owns one (env, entity) and walks the egos; rows are 28 B, so the stores are scalar.
-        float* base = p.o.node_obs + (size_t)n0 * A * E * 7;
+        float* base = o.node_obs + (size_t)n0 * A * E * 7;
         for (int sidx = t0; sidx < Gv * E; sidx += nthr) {
             const int gg = fdiv(sidx, E, p.m_E), k = sidx - gg * E;
             if (!l.flags[gg * 4 + 3]) continue;
@@ -510,10 +523,10 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, 
             }
         }
     }
-    if (!sc_rotfam(SC) && p.o.node_obs && !(abl & 2)) {
+    if (!sc_rotfam(SC) && o.node_obs && !(abl & 2)) {
         // node row (ego, entity k) = 2 float4: [rel_vel, rel_pos] and [rel_goal, occupied, type].
         // A lane owns one (env, entity, half) slot, keeps that entity's data in registers and walks the egos.
-        float4* base = reinterpret_cast<float4*>(p.o.node_obs + (size_t)n0 * A * E * GMPE_NODE_FEATS);
+        float4* base = reinterpret_cast<float4*>(o.node_obs + (size_t)n0 * A * E * GMPE_NODE_FEATS);
         const int E2 = 2 * E;
         for (int sidx = t0; sidx < Gv * E2; sidx += nthr) {
             const int gg = fdiv(sidx, E2, p.m_2E), rem = sidx - gg * E2;
@@ -570,7 +583,8 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const Lds& l, 
 // FL = 1: the steady-state instantiation — step mode, wave specialisation on, ordinary stores, no ablation — with those run-time
 // flags folded (selected by the host when they hold; everything else takes FL = 0).
 template <int BLOCK, int AP, int SC, int FL>
-__global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP > 0 && BLOCK > 64 ? (sc_rotfam(SC) ? 3 : 4) : GMPE_MIN_WAVES_NOWALLS))) void k_env(const KParams p) {
+__global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL == 2 && BLOCK > 64 ? (sc_phasefam(SC) ? 2 : 3) : (AP > 0 && BLOCK > 64 ? (sc_rotfam(SC) ? 3 : 4) : GMPE_MIN_WAVES_NOWALLS)))) void k_env(const KParams p_arg) {
+    const KParams& p = p_arg;
     constexpr bool WALLS = SC == SC_NAV_WALLS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     {   // Touch every 64-byte line of the 1.1 KB kernarg segment at once: the compiler fetches kernel parameters right before each
@@ -605,13 +619,10 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP >
     if (ag && !step && p.mask && !p.mask[n]) ag = false;               // explicit reset: masked-out env
     const size_t na = (size_t)n * A + i;
     const Lds v = env_view(l, ag ? g : 0, A, E, D);
-    const unsigned long long emask = ag ? ((A >= 64 ? ~0ull : ((1ull << A) - 1ull)) << (g * A)) : 0ull;
 
     // ---- per-agent registers
     int prev_phase = 0, phase_reached = 0, cooldown = 0;
     double p_dist = 0, tim = 0;
-    int trq = -1, dtg = -1, dleft = -1, greached = -1, nac = 0, noc = 0, sv = 0, sic = 0, conf = 0;
-    double gmt = 0, dsp0 = 0, pproj = 0;
     int cur_step = 0, act_idx = 0;
     int err = 0;
     int64_t ctr0 = 0;
@@ -693,502 +704,596 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP >
     __syncthreads();
     STAMP(1);
 
-    int ph1 = 0, cp = 0, prevA = 0;
-    bool goal_branch = true, done = false, all_done = false;
-    double dgoal = 0, rew = 0;
-    if (step) {
-        cur_step += 1;
-        const int C = A + O;                                            // colliders: agents + obstacles (landmarks collide=False)
-        double* Fx = reinterpret_cast<double*>(l.M);                    // pair forces alias the (not yet built) fp32 matrix
-        double* Fy = Fx + (size_t)G * A * C;
-        if (!kin) {
-            // ---- 1a. contact forces, one PAIR per lane (get_entity_collision_force core.py:872-906): pair (a, k>a)
-            // computed once with delta = pos[a]-pos[k]; side a gets +F, side k gets -F (summed in 1b).
-            const int NP = A * (A - 1) / 2, W = NP + A * O;            // valid pairs only: agent pairs (a<k) + agent x obstacle
-            // One pair per lane and trip; only the waves that still own a pair run another trip (C2: 270 pairs on 256 lanes —
-            // the 14-pair tail costs one wave, not four). Branch-free: nearly every wave holds a pair inside the softplus
-            // range; far pairs get pen = log1p(exp(-large)) = 0 like in the reference.
-            for (int q = tid; q < Gv * W; q += BLOCK) {
-                if (!FL && (p.ablate & 8)) { Fx[q] = 0.0; Fy[q] = 0.0; continue; }   // timing diagnostic only (wrong results)
-                const int gg = fdiv(q, W, p.m_FW), w = q - gg * W;
-                const bool apair = w < NP;
-                const int pk = l.ptab[apair ? w : 0];
-                const int t = apair ? 0 : w - NP;
-                const int ao = fdiv(t, O, p.m_O);
-                const int a = apair ? (pk >> 8) : ao, kk = apair ? (pk & 255) : A + (t - ao * O);
-                const int k = kk < A ? kk : L + kk;                     // entity index of collider kk
-                const double dx = l.ex[gg * E + a] - l.ex[gg * E + k], dy = l.ey[gg * E + a] - l.ey[gg * E + k];
-                const double dist = sqrt(dx * dx + dy * dy);
-                const double pen = logaddexp0(-(dist - c.sep_dist) / c.contact_margin) * c.contact_margin;
-                const int slot = gg * A * C + a * C + kk;
-                Fx[slot] = c.contact_force * dx / dist * pen; Fy[slot] = c.contact_force * dy / dist * pen;
-            }
-            if (WALLS) {
-                // wall contact forces (get_wall_collision_force core.py:909-964), one (agent, wall) per lane: the asin / cos /
-                // softplus code lives here instead of in the agent lane's dynamics (187 -> 141 VGPRs for the walls variant)
-                const int NW = c.num_walls;
-                for (int q = tid; q < Gv * A * NW; q += BLOCK) {
-                    const int slot = q / NW, w = q - slot * NW;         // slot = tile-level agent index (gg*A + a)
-                    const int gg = fdiv(slot, A, p.m_A), a = slot - gg * A;
-                    double wx = 0.0, wy = 0.0;
-                    if (!wall_force(c.walls[w], l.ex[gg * E + a], l.ey[gg * E + a], c.entity_size, c.wall_contact_force, c.wall_contact_margin, wx, wy)) { wx = 0.0; wy = 0.0; }
-                    l.fw[(size_t)slot * 2 * NW + 2 * w] = wx; l.fw[(size_t)slot * 2 * NW + 2 * w + 1] = wy;   // None -> +0.0: x + 0.0 == x
-                }
-            }
-            __syncthreads();
+    // FL == 2 (gmpe_rollout_steps): the K steps of an open-loop rollout run inside this launch. A tile's step k+1 depends only on the
+    // tile's own state, which stays in LDS / registers between steps (no state reload, write-back after the last step only); the
+    // graph stores of step k drain while the tile — and the other tiles of the CU, which drift out of phase — run step k+1's
+    // latency chain. Every other instantiation runs the body once.
+    constexpr bool ROLL = FL == 2;
+    const int K = ROLL ? p.K : 1;
+    int slot = ROLL ? p.first_slot : 0, aset = 0;
+    const int tid_o = tid; const bool ag_o = ag;
+    int kk = 0;
+    do {                                                                    // `while (ROLL && ...)`: no loop at all in the other instantiations
+        // Rollouts hide the lane index from the optimiser once per step: everything below is a function of it, and loop-invariant
+        // code motion would otherwise hoist a whole step's worth of index / address arithmetic out of the loop and keep it in
+        // registers (256 VGPRs instead of ~125).
+        int tid_k = tid_o;
+        const KParams __attribute__((address_space(4)))* pk = (const KParams __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+        if (ROLL) { asm volatile("" : "+v"(tid_k)); asm volatile("" : "+s"(pk)); }   // same for the kernel parameters: uniform fp64 expressions of the config live in VGPR pairs
+        const int tid = tid_k;
+        const KParams& p = ROLL ? *(const KParams*)pk : p_arg;              // the kernel's only argument sits at offset 0 of the kernarg segment
+        const gmpe_config& c = p.c;
+        const int g = fdiv(tid, A, p.m_A), i = tid - g * A;
+        const int n = n0 + g;
+        const bool ag = ROLL ? tid < Gv * A : ag_o;
+        const size_t na = (size_t)n * A + i;
+        const Lds v = env_view(l, ag ? g : 0, A, E, D);
+        const unsigned long long emask = ag ? ((A >= 64 ? ~0ull : ((1ull << A) - 1ull)) << (g * A)) : 0ull;
+        gmpe_outputs out_k;                                                 // rollouts: this step's slot of every output
+        const gmpe_outputs& out = ROLL ? out_k : p.o;
+        int act_next = 0;
+        if (ROLL) {
+            // this step's output slot, and the next step's actions (issued now, consumed at the top of the next iteration)
+            out_k = p.o;
+            if (out_k.obs) out_k.obs += (size_t)slot * p.st_obs;
+            if (out_k.agent_id) out_k.agent_id += (size_t)slot * p.st_id;
+            if (out_k.node_obs) out_k.node_obs += (size_t)slot * p.st_node;
+            if (out_k.adj) out_k.adj += (size_t)slot * p.st_adj;
+            if (out_k.reward) out_k.reward += (size_t)slot * p.st_rew;
+            if (out_k.done) out_k.done += (size_t)slot * p.st_done;
+            if (out_k.info) out_k.info += (size_t)slot * p.st_info;
+            const int anext = aset + 1 == p.S ? 0 : aset + 1;
+            if (ag && kk + 1 < K) act_next = p.act[(size_t)anext * N * A + na];
+            aset = anext;
         }
-        STAMP(2);
-        // ---- 1b. action decode + dynamics
-        double nx = 0, ny = 0, nv2 = 0, nv3 = 0;
-        if (ag) {
-            double u0, u1; decode_action<SC>(c, act_idx, u0, u1);
-            nx = v.ex[i]; ny = v.ey[i]; nv2 = v.s2[i]; nv3 = v.s3[i];
-            if (kin) {
-                if (!v.s_old[i]) {                                      // update_agent_state core.py:819-826
-                    const double dt = c.dt, th0 = nv2, v0 = nv3;
-                    const double th1 = th0 + u0 * dt, v1 = v0 + u1 * dt;
-                    if (u0 != 0.0) {
-                        double s0, c0, s1, c1; sincos(th0, &s0, &c0); sincos(th1, &s1, &c1);
-                        nx += (v1 * s1 - v0 * s0) / u0 + u1 * (c1 - c0) / (u0 * u0);
-                        ny += (-v1 * c1 + v0 * c0) / u0 + u1 * (s1 - s0) / (u0 * u0);
-                    } else {
-                        const double d = (v0 + 0.5 * u1 * dt) * dt;
-                        double s0, c0; sincos(th0, &s0, &c0);
-                        nx += d * c0; ny += d * s0;
-                    }
-                    double vv = v1;
-                    if (vv > c.v_max) vv = c.v_max;
-                    if (vv < c.v_min) vv = c.v_min;
-                    nv2 = th1; nv3 = vv;
-                    p_dist += vv * dt; tim += dt;
-                }
-            } else {
-                // force path core.py:766-845: accumulate in the reference's order for this agent — other
-                // entities by ascending index (side b below its own index, side a above), then walls.
-                double sx = 1.0 * u0, sy = 1.0 * u1;
-                const double* fxg = Fx + (size_t)g * A * C; const double* fyg = Fy + (size_t)g * A * C;
-                const bool ego_live = v.s_old[i] == 0;                  // done side gets no agent-agent force (899-900)
-                SWEEP(k, A) {
-                    const bool ok = !AP || k < A;
-                    const int kc = ok ? k : 0;
-                    const bool below = kc < i;
-                    const int idx = below ? kc * C + i : i * C + kc;
-                    const double fx = fxg[idx], fy = fyg[idx];
-                    const bool use = ok && ego_live && kc != i && (fx != 0.0 || fy != 0.0);
-                    sx = use ? ((below ? -fx : fx) + sx) : sx;
-                    sy = use ? ((below ? -fy : fy) + sy) : sy;
-                }
-                for (int o = 0; o < O; ++o) {                           // immovable obstacles push regardless of status
-                    const double fx = fxg[i * C + A + o], fy = fyg[i * C + A + o];
-                    if (fx != 0.0 || fy != 0.0) { sx = fx + sx; sy = fy + sy; }
+        int ph1 = 0, cp = 0, prevA = 0, ndraw = 0;
+        bool goal_branch = true, done = false, all_done = false;
+        double dgoal = 0, rew = 0;
+        int trq = -1, dtg = -1, dleft = -1, greached = -1, nac = 0, noc = 0, sv = 0, sic = 0, conf = 0;   // info counters: staged in LDS, live inside one step only
+        double gmt = 0, dsp0 = 0, pproj = 0;
+        if (step) {
+            cur_step += 1;
+            const int C = A + O;                                            // colliders: agents + obstacles (landmarks collide=False)
+            double* Fx = reinterpret_cast<double*>(l.M);                    // pair forces alias the (not yet built) fp32 matrix
+            double* Fy = Fx + (size_t)G * A * C;
+            if (!kin) {
+                // ---- 1a. contact forces, one PAIR per lane (get_entity_collision_force core.py:872-906): pair (a, k>a)
+                // computed once with delta = pos[a]-pos[k]; side a gets +F, side k gets -F (summed in 1b).
+                const int NP = A * (A - 1) / 2, W = NP + A * O;            // valid pairs only: agent pairs (a<k) + agent x obstacle
+                // One pair per lane and trip; only the waves that still own a pair run another trip (C2: 270 pairs on 256 lanes —
+                // the 14-pair tail costs one wave, not four). Branch-free: nearly every wave holds a pair inside the softplus
+                // range; far pairs get pen = log1p(exp(-large)) = 0 like in the reference.
+                for (int q = tid; q < Gv * W; q += BLOCK) {
+                    if (!FL && (GMPE_ABL(p) & 8)) { Fx[q] = 0.0; Fy[q] = 0.0; continue; }   // diagnostic build only
+                    const int gg = fdiv(q, W, p.m_FW), w = q - gg * W;
+                    const bool apair = w < NP;
+                    const int pk = l.ptab[apair ? w : 0];
+                    const int t = apair ? 0 : w - NP;
+                    const int ao = fdiv(t, O, p.m_O);
+                    const int a = apair ? (pk >> 8) : ao, kk = apair ? (pk & 255) : A + (t - ao * O);
+                    const int k = kk < A ? kk : L + kk;                     // entity index of collider kk
+                    const double dx = l.ex[gg * E + a] - l.ex[gg * E + k], dy = l.ey[gg * E + a] - l.ey[gg * E + k];
+                    const double dist = sqrt(dx * dx + dy * dy);
+                    const double pen = logaddexp0(-(dist - c.sep_dist) / c.contact_margin) * c.contact_margin;
+                    const int slot = gg * A * C + a * C + kk;
+                    Fx[slot] = c.contact_force * dx / dist * pen; Fy[slot] = c.contact_force * dy / dist * pen;
                 }
                 if (WALLS) {
-                    const double* fwi = l.fw + (size_t)(g * A + i) * 2 * c.num_walls;
-                    for (int w = 0; w < c.num_walls; ++w) { sx = sx + fwi[2 * w]; sy = sy + fwi[2 * w + 1]; }
+                    // wall contact forces (get_wall_collision_force core.py:909-964), one (agent, wall) per lane: the asin / cos /
+                    // softplus code lives here instead of in the agent lane's dynamics (187 -> 141 VGPRs for the walls variant)
+                    const int NW = c.num_walls;
+                    for (int q = tid; q < Gv * A * NW; q += BLOCK) {
+                        const int slot = q / NW, w = q - slot * NW;         // slot = tile-level agent index (gg*A + a)
+                        const int gg = fdiv(slot, A, p.m_A), a = slot - gg * A;
+                        double wx = 0.0, wy = 0.0;
+                        if (!wall_force(c.walls[w], l.ex[gg * E + a], l.ey[gg * E + a], c.entity_size, c.wall_contact_force, c.wall_contact_margin, wx, wy)) { wx = 0.0; wy = 0.0; }
+                        l.fw[(size_t)slot * 2 * NW + 2 * w] = wx; l.fw[(size_t)slot * 2 * NW + 2 * w + 1] = wy;   // None -> +0.0: x + 0.0 == x
+                    }
                 }
-                double vx = nv2 * (1 - c.damping), vy = nv3 * (1 - c.damping);
-                vx += (sx / 1.0) * c.dt; vy += (sy / 1.0) * c.dt;
-                if (c.max_speed > 0) {
-                    const double sp = sqrt(vx * vx + vy * vy);
-                    if (sp > c.max_speed) { vx = vx / sp * c.max_speed; vy = vy / sp * c.max_speed; }
-                }
-                nv2 = vx; nv3 = vy;
-                nx += vx * c.dt; ny += vy * c.dt;
-                const double ax = vx * c.dt, ay = vy * c.dt;
-                p_dist += sqrt(ax * ax + ay * ay); tim += c.dt;
+                __syncthreads();
             }
-            v.ex[i] = nx; v.ey[i] = ny; v.s2[i] = nv2; v.s3[i] = nv3;   // nobody reads positions between 1a and here
-        }
-        __syncthreads();
-        STAMP(3);
-        distance_pass<BLOCK, (CT ? AP : 0)>(p, l, Gv, tid, false);                    // post-move rows: obs, reward, info, adj all read these
-        __syncthreads();
-        STAMP(4);
-
-        // ---- 2. phase FSM + who newly reaches the goal (depends only on own data: SURVEY §8a)
-        prevA = prev_phase;
-        if (ag) {
-            const double px = v.ex[i], py = v.ey[i];
-            double vx, vy; vel_of<SC>(v.s2[i], v.s3[i], vx, vy);
-            v.vox[i] = vx; v.voy[i] = vy;
-            if (july) {
-                ph1 = phase_eval(v.tube, px, py, prev_phase, prevA);     // observation's call (:1447)
-                if (cooldown > 0) cooldown -= 1;
-                int prevB;
-                cp = phase_eval(v.tube, px, py, prevA, prevB);           // reward's call (:1113)
-                if (cooldown > 0) cooldown -= 1;
-                prevA = prevB;
-                goal_branch = (cp == 2 && phase_reached != 0);
-            } else if (rotfam) {
-                // rot_inv.py:675-739: the query mutates only the cooldown, so observation's and reward's calls agree;
-                // phase 2 is only returned with phase_reached >= 1, hence the goal block runs iff cp == 2 (:1281-1297).
-                // three_phase has no demotion either (:1110); in two_phase the agent finishes at the 1 -> 2 transition.
-                ph1 = phase_eval_rot<PV>(v.tube, px, py, prev_phase, phase_reached);
-                if (cooldown > 0) cooldown -= 1;
-                if (cooldown > 0) cooldown -= 1;
-                cp = ph1;
-                goal_branch = (cp == 2) && (rotinv ? phase_reached >= 1 : true);
-            }
-            dgoal = v.Dm[(size_t)i * E + A + i];
-            if (two) v.newf[i] = cp == 2 && prev_phase == 1 && phase_reached == 1 && !v.s_old[i];   // two_phase_graph.py:1023-1044
-            else v.newf[i] = goal_branch && dgoal < c.goal_thresh && !v.s_old[i];
-        }
-        // rank of each newly-reached agent among its env's: heading re-draws follow agent order (core.py:328)
-        if (tid < 64) {
-            const unsigned long long bal = __ballot(ag && v.newf[i]);
+            STAMP(2);
+            // ---- 1b. action decode + dynamics
+            double nx = 0, ny = 0, nv2 = 0, nv3 = 0;
             if (ag) {
-                if (v.newf[i]) {
-                    const int rank = __popcll(bal & emask & ((1ull << tid) - 1ull));
-                    if (kin) { v.n2[i] = 0.0 + (2 * M_PI - 0.0) * draw_at(c, p.s, n, ctr0 + rank, err); v.n3[i] = c.v_min; }
-                    else { v.n2[i] = 0.0; v.n3[i] = 0.0; }
-                    if (!two && !three) v.gt[i] = i;                          // the phase-graph files never write goal_tracker (three_phase_graph.py:1119)
-                    double vx, vy; vel_of<SC>(v.n2[i], v.n3[i], vx, vy);
-                    v.vnx[i] = vx; v.vny[i] = vy;
-                } else { v.n2[i] = v.s2[i]; v.n3[i] = v.s3[i]; v.vnx[i] = v.vox[i]; v.vny[i] = v.voy[i]; }
-                if (rotfam) { double sn_, cn_; sincos(v.n2[i], &sn_, &cn_); v.cn[i] = cn_; v.sn[i] = sn_; }
-                if (i == 0) v.flags[1] = kin ? __popcll(bal & emask) : 0;   // draws consumed (DI reset_velocity draws none)
-                // done flag (_get_done environment.py:264-271) and this step's adjacency mask (…_july.py:1627-1648:
-                // done agents, reached landmarks) depend only on status / goal_tracker: known before the rewards
-                const bool st_now = v.s_old[i] || v.newf[i];
-                done = st_now || cur_step >= c.episode_length;
-                v.moff[i] = st_now ? 1 : 0; v.moff[A + i] = (v.gt[i] == i) ? 1 : 0;
-            }
-            // all agents of an env done -> the worker resets it (env_wrappers.py:865-870)
-            const unsigned long long dbal = __ballot(ag && done);
-            const unsigned long long mbal = __ballot(ag && (v.moff[i] | v.moff[A + i]));
-            all_done = ag && ((dbal & emask) == emask);
-            if (ag && i == 0) { v.flags[0] = all_done; v.flags[2] = (mbal & emask) != 0ull; }
-        }
-        __syncthreads();
-        STAMP(5);
-    }
-
-
-    int any_reset = 0, any_mask = 0;
-    for (int gg = 0; gg < Gv; ++gg) { any_reset |= l.flags[gg * 4 + 0]; any_mask |= l.flags[gg * 4 + 2]; }   // block-uniform
-    const int abl = FL ? 0 : p.ablate;
-
-
-    // Common case (no env of the tile resets): issue the 22 KB/env of graph stores FIRST, then do the reward /
-    // info arithmetic under the HBM write drain. Tiles with a reset need the terminal reward/info before the
-    // reset overwrites the LDS state, so they keep the reference's order.
-    const bool early = step && !any_reset;
-    // Multi-wave tiles specialise: wave 0 (all agent lanes) does reward / info / write-back while waves 1.. stream the
-    // graph observations, so the ~7 us of per-agent arithmetic runs beside the store issue instead of after it.
-    const bool spec = early && BLOCK > 64 && (FL ? true : p.spec != 0);
-    if (early && !spec) stream_graph_fn<BLOCK, AP, SC, FL>(p, l, Gv, n0, tid, tid, BLOCK, true, any_mask);
-    if (spec) {
-        if (any_mask && !(abl & 4)) {
-            for (int q = tid; q < Gv * EE; q += BLOCK) {
-                const int gg = fdiv(q, EE, p.m_EE), rc = q - gg * EE;
-                if (!l.flags[gg * 4 + 2]) continue;
-                const int r = fdiv(rc, E, p.m_E), cc = rc - r * E;
-                if (l.moff[gg * E + r] | l.moff[gg * E + cc]) l.M[(size_t)gg * EE4 + rc] = 0.0f;
-            }
-        }
-        __syncthreads();
-    }
-    if (step) {
-        if (!spec || tid < 64) {
-            // ---- sections 3+4 (obs, reward, info, write-back). In specialised tiles only wave 0 gets here and the
-            // block barrier between the two sections is replaced by wave-local ordering.
-            const bool block_sync = !spec;
-            // ---- 3. obs, reward, done (ego i sees agent k done iff s_old[k] || (new[k] && k < i))
-            rew = 0;
-            if (ag) {
-                {   // staged info counters (LDS reads: unaffected by the HBM write drain that has started)
-                    const int* ci = l.cnt + (size_t)(g * A + i) * 9;
-                    trq = ci[0]; dtg = ci[1]; dleft = ci[2]; greached = ci[3]; nac = ci[4]; noc = ci[5]; sv = ci[6]; sic = ci[7]; conf = ci[8];
-                    gmt = l.cntd[(size_t)(g * A + i) * 2]; if (rotinv) pproj = l.cntd[(size_t)(g * A + i) * 2 + 1];
-                    dsp0 = l.cntd[(size_t)G * A * 2 + g];
+                double u0, u1; decode_action<SC>(c, act_idx, u0, u1);
+                nx = v.ex[i]; ny = v.ey[i]; nv2 = v.s2[i]; nv3 = v.s3[i];
+                if (kin) {
+                    if (!v.s_old[i]) {                                      // update_agent_state core.py:819-826
+                        const double dt = c.dt, th0 = nv2, v0 = nv3;
+                        const double th1 = th0 + u0 * dt, v1 = v0 + u1 * dt;
+                        if (u0 != 0.0) {
+                            double s0, c0, s1, c1; sincos(th0, &s0, &c0); sincos(th1, &s1, &c1);
+                            nx += (v1 * s1 - v0 * s0) / u0 + u1 * (c1 - c0) / (u0 * u0);
+                            ny += (-v1 * c1 + v0 * c0) / u0 + u1 * (s1 - s0) / (u0 * u0);
+                        } else {
+                            const double d = (v0 + 0.5 * u1 * dt) * dt;
+                            double s0, c0; sincos(th0, &s0, &c0);
+                            nx += d * c0; ny += d * s0;
+                        }
+                        double vv = v1;
+                        if (vv > c.v_max) vv = c.v_max;
+                        if (vv < c.v_min) vv = c.v_min;
+                        nv2 = th1; nv3 = vv;
+                        p_dist += vv * dt; tim += dt;
+                    }
+                } else {
+                    // force path core.py:766-845: accumulate in the reference's order for this agent — other
+                    // entities by ascending index (side b below its own index, side a above), then walls.
+                    double sx = 1.0 * u0, sy = 1.0 * u1;
+                    const double* fxg = Fx + (size_t)g * A * C; const double* fyg = Fy + (size_t)g * A * C;
+                    const bool ego_live = v.s_old[i] == 0;                  // done side gets no agent-agent force (899-900)
+                    SWEEP(k, A) {
+                        const bool ok = !AP || k < A;
+                        const int kc = ok ? k : 0;
+                        const bool below = kc < i;
+                        const int idx = below ? kc * C + i : i * C + kc;
+                        const double fx = fxg[idx], fy = fyg[idx];
+                        const bool use = ok && ego_live && kc != i && (fx != 0.0 || fy != 0.0);
+                        sx = use ? ((below ? -fx : fx) + sx) : sx;
+                        sy = use ? ((below ? -fy : fy) + sy) : sy;
+                    }
+                    for (int o = 0; o < O; ++o) {                           // immovable obstacles push regardless of status
+                        const double fx = fxg[i * C + A + o], fy = fyg[i * C + A + o];
+                        if (fx != 0.0 || fy != 0.0) { sx = fx + sx; sy = fy + sy; }
+                    }
+                    if (WALLS) {
+                        const double* fwi = l.fw + (size_t)(g * A + i) * 2 * c.num_walls;
+                        for (int w = 0; w < c.num_walls; ++w) { sx = sx + fwi[2 * w]; sy = sy + fwi[2 * w + 1]; }
+                    }
+                    double vx = nv2 * (1 - c.damping), vy = nv3 * (1 - c.damping);
+                    vx += (sx / 1.0) * c.dt; vy += (sy / 1.0) * c.dt;
+                    if (c.max_speed > 0) {
+                        const double sp = sqrt(vx * vx + vy * vy);
+                        if (sp > c.max_speed) { vx = vx / sp * c.max_speed; vy = vy / sp * c.max_speed; }
+                    }
+                    nv2 = vx; nv3 = vy;
+                    nx += vx * c.dt; ny += vy * c.dt;
+                    const double ax = vx * c.dt, ay = vy * c.dt;
+                    p_dist += sqrt(ax * ax + ay * ay); tim += c.dt;
                 }
+                v.ex[i] = nx; v.ey[i] = ny; v.s2[i] = nv2; v.s3[i] = nv3;   // nobody reads positions between 1a and here
+            }
+            __syncthreads();
+            STAMP(3);
+            distance_pass<BLOCK, (CT ? AP : 0)>(p, l, Gv, tid, false);                    // post-move rows: obs, reward, info, adj all read these
+            __syncthreads();
+            STAMP(4);
+
+            // ---- 2. phase FSM + who newly reaches the goal (depends only on own data: SURVEY §8a)
+            prevA = prev_phase;
+            if (ag) {
                 const double px = v.ex[i], py = v.ey[i];
-                const double* row = v.Dm + (size_t)i * E;
-                if (rotfam) write_obs_rot<AP, SC>(p, v, i, ph1); else write_obs<AP, SC>(p, v, i, v.vox[i], v.voy[i], ph1);
-                STAMP(13);
-                // collision block (…_july.py:1117-1124) and info_callback's collision count (:780-786) in one sweep
-                int ncol_r = 0, ncol_i = 0;
-                const bool me_old = v.s_old[i] != 0, me_new = v.newf[i] != 0;
-                if (AP) {                                                  // all LDS reads of the sweep first, then the arithmetic
-                    double rv[AP ? AP : 1]; int so[AP ? AP : 1], nf[AP ? AP : 1];
-    #pragma unroll
-                    for (int a = 0; a < AP; ++a) { const int ac = a < A ? a : 0; rv[a] = row[ac]; so[a] = v.s_old[ac]; nf[a] = v.newf[ac]; }
-                    __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
-                    for (int a = 0; a < AP; ++a) {
-                        const bool close = a < A && rv[a] < c.sep_dist && a != i;
-                        ncol_r += (close && !so[a] && !(nf[a] && a < i)) ? 1 : 0;
-                        ncol_i += (close && !so[a] && !(nf[a] && a <= i)) ? 1 : 0;
-                    }
-                } else {
-                    for (int a = 0; a < A; ++a) {
-                        const bool close = row[a] < c.sep_dist && a != i;
-                        const int so = v.s_old[a], nf = v.newf[a];
-                        ncol_r += (close && !so && !(nf && a < i)) ? 1 : 0;
-                        ncol_i += (close && !so && !(nf && a <= i)) ? 1 : 0;
-                    }
-                }
-                if (me_old) { ncol_r = 0; }
-                if (me_old || me_new) ncol_i = 0;
-                // reward term per contact: 4 x collision_rew (…_july.py:1117-1124, rot_inv.py:1134-1139); three_phase_graph.py:965-970: 1 x;
-                // two_phase_graph.py: none (block commented out)
-                if (three) { for (int q = 0; q < ncol_r; ++q) rew -= c.collision_rew; }
-                else if (!two) for (int q = 0; q < ncol_r; ++q) rew -= c.collision_rew * 4;
-                nac += ncol_i;
-                STAMP(14);
-                const bool obst_hit = obstacle_collision_ego(p, v, i);
-                if (obst_hit) { if (!two && !three) rew -= c.collision_rew * 3; noc += 1; }
-                double serr = 0;
+                double vx, vy; vel_of<SC>(v.s2[i], v.s3[i], vx, vy);
+                v.vox[i] = vx; v.voy[i] = vy;
                 if (july) {
-                    const double tdx = v.tube[T_EXX] - v.tube[T_ENTX], tdy = v.tube[T_EXY] - v.tube[T_ENTY];
-                    const double tlen = sqrt(tdx * tdx + tdy * tdy);
-                    if (cp == 2 && cp > prevA + 1) rew -= c.goal_rew * 3;
-                    const double ux = tdx / tlen, uy = tdy / tlen;
-                    const double qx = px - v.tube[T_ENTX], qy = py - v.tube[T_ENTY];
-                    const double proj = qx * ux + qy * uy;
-                    if (cp == prevA + 1 && phase_reached == cp - 1) {
-                        if (cp == 1) {
-                            const double edist = norm2(qx - proj * tdx, qy - proj * tdy);   // un-normalised (:1154)
-                            if (0 <= proj && proj < 0.1 * tlen && edist < 0.2 * tlen) rew += c.goal_rew * 3;
-                        } else if (cp == 2) rew += c.goal_rew * 3;
-                    }
-                    if (cp == 0) rew -= norm2(v.tube[T_ENTX] - px, v.tube[T_ENTY] - py);
-                    else if (cp == 1) {
-                        double hx, hy; sincos(v.s2[i], &hy, &hx);
-                        int front = -1, back = -1; double fproj = 0, bproj = 0;
-                        for (int k = 0; k < A; ++k) {                       // 1136-1143, first wins ties
-                            if (k == i) continue;
-                            const double pj = (v.ex[k] - px) * hx + (v.ey[k] - py) * hy;
-                            if (pj > 0) { if (front < 0 || pj < fproj) { front = k; fproj = pj; } }
-                            else { if (back < 0 || pj > bproj) { back = k; bproj = pj; } }
-                        }
-                        if (front >= 0) { const double df = row[front] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
-                        if (back >= 0) { const double df = row[back] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
-                        if (serr > 0) sv += 1;
-                        rew -= serr * c.formation_rew;
-                        rew -= norm2(v.tube[T_EXX] - px, v.tube[T_EXY] - py);
-                        sic += 1;
-                    } else if (cp == 2 && phase_reached == 0) cp = 0;
-                    else {
-                        if (dgoal < c.goal_thresh) { if (me_new) rew += c.goal_rew * 5; }
-                        else rew -= dgoal;
-                    }
-                    if (phase_reached == 1 && cp == 0) conf += 1;
-                    if (cp > phase_reached) phase_reached = cp;
-                    if (cp < prevA) rew -= c.collision_rew * 3;
-                    if (cp < phase_reached) rew -= c.collision_rew;
-                    prev_phase = cp;
+                    ph1 = phase_eval(v.tube, px, py, prev_phase, prevA);     // observation's call (:1447)
+                    if (cooldown > 0) cooldown -= 1;
+                    int prevB;
+                    cp = phase_eval(v.tube, px, py, prevA, prevB);           // reward's call (:1113)
+                    if (cooldown > 0) cooldown -= 1;
+                    prevA = prevB;
+                    goal_branch = (cp == 2 && phase_reached != 0);
                 } else if (rotfam) {
-                    // Scenario.reward, rot_inv.py:1122-1338; two_phase_graph.py:955-1142; three_phase_graph.py:957-1160
-                    const double Lt = v.tube[T_L], hw = v.tube[T_HALFW];
-                    double ts, ty; tube_sy(v.tube, px, py, ts, ty);
-                    if (cp == 2 && cp > prev_phase + 1) rew -= c.goal_rew;
-                    if (cp == prev_phase + 1 && phase_reached == cp - 1) {
-                        if (cp == 1 && in_entrance_gate(ts, ty, Lt, hw) && cooldown == 0) {
-                            rew += c.goal_rew;
-                            // rot_inv: episode_length/10 as a float into an int32 array (:1200, :228); phase graphs: episode_length
-                            cooldown = (two || three) ? c.episode_length : (int)((double)c.episode_length / 10);
-                            phase_reached = 1;
-                        } else if (cp == 2) {
-                            rew += c.goal_rew; phase_reached = 2;
-                            if (two && me_new) rew += c.goal_rew * 5;                               // finished at the exit gate (:1040-1044)
+                    // rot_inv.py:675-739: the query mutates only the cooldown, so observation's and reward's calls agree;
+                    // phase 2 is only returned with phase_reached >= 1, hence the goal block runs iff cp == 2 (:1281-1297).
+                    // three_phase has no demotion either (:1110); in two_phase the agent finishes at the 1 -> 2 transition.
+                    ph1 = phase_eval_rot<PV>(v.tube, px, py, prev_phase, phase_reached);
+                    if (cooldown > 0) cooldown -= 1;
+                    if (cooldown > 0) cooldown -= 1;
+                    cp = ph1;
+                    goal_branch = (cp == 2) && (rotinv ? phase_reached >= 1 : true);
+                }
+                dgoal = v.Dm[(size_t)i * E + A + i];
+                if (two) v.newf[i] = cp == 2 && prev_phase == 1 && phase_reached == 1 && !v.s_old[i];   // two_phase_graph.py:1023-1044
+                else v.newf[i] = goal_branch && dgoal < c.goal_thresh && !v.s_old[i];
+            }
+            // rank of each newly-reached agent among its env's: heading re-draws follow agent order (core.py:328)
+            if (tid < 64) {
+                const unsigned long long bal = __ballot(ag && v.newf[i]);
+                if (ag) {
+                    if (v.newf[i]) {
+                        const int rank = __popcll(bal & emask & ((1ull << tid) - 1ull));
+                        if (kin) { v.n2[i] = 0.0 + (2 * M_PI - 0.0) * draw_at(c, p.s, n, ctr0 + rank, err); v.n3[i] = c.v_min; }
+                        else { v.n2[i] = 0.0; v.n3[i] = 0.0; }
+                        if (!two && !three) v.gt[i] = i;                          // the phase-graph files never write goal_tracker (three_phase_graph.py:1119)
+                        double vx, vy; vel_of<SC>(v.n2[i], v.n3[i], vx, vy);
+                        v.vnx[i] = vx; v.vny[i] = vy;
+                    } else { v.n2[i] = v.s2[i]; v.n3[i] = v.s3[i]; v.vnx[i] = v.vox[i]; v.vny[i] = v.voy[i]; }
+                    if (rotfam) { double sn_, cn_; sincos(v.n2[i], &sn_, &cn_); v.cn[i] = cn_; v.sn[i] = sn_; }
+                    ndraw = kin ? __popcll(bal & emask) : 0;                  // draws consumed (DI reset_velocity draws none)
+                    if (i == 0) v.flags[1] = ndraw;
+                    // done flag (_get_done environment.py:264-271) and this step's adjacency mask (…_july.py:1627-1648:
+                    // done agents, reached landmarks) depend only on status / goal_tracker: known before the rewards
+                    const bool st_now = v.s_old[i] || v.newf[i];
+                    done = st_now || cur_step >= c.episode_length;
+                    v.moff[i] = st_now ? 1 : 0; v.moff[A + i] = (v.gt[i] == i) ? 1 : 0;
+                }
+                // all agents of an env done -> the worker resets it (env_wrappers.py:865-870)
+                const unsigned long long dbal = __ballot(ag && done);
+                const unsigned long long mbal = __ballot(ag && (v.moff[i] | v.moff[A + i]));
+                all_done = ag && ((dbal & emask) == emask);
+                if (ag && i == 0) { v.flags[0] = all_done; v.flags[2] = (mbal & emask) != 0ull; }
+            }
+            __syncthreads();
+            STAMP(5);
+        }
+
+
+        int any_reset = 0, any_mask = 0;
+        for (int gg = 0; gg < Gv; ++gg) { any_reset |= l.flags[gg * 4 + 0]; any_mask |= l.flags[gg * 4 + 2]; }   // block-uniform
+        const int abl = FL ? 0 : GMPE_ABL(p);
+
+        // Common case (no env of the tile resets): issue the 22 KB/env of graph stores FIRST, then do the reward /
+        // info arithmetic under the HBM write drain. Tiles with a reset need the terminal reward/info before the
+        // reset overwrites the LDS state, so they keep the reference's order.
+        const bool early = step && !any_reset;
+        // Multi-wave tiles specialise: wave 0 (all agent lanes) does reward / info / write-back while waves 1.. stream the
+        // graph observations, so the ~7 us of per-agent arithmetic runs beside the store issue instead of after it.
+        const bool spec = early && BLOCK > 64 && (FL ? true : p.spec != 0);
+        if (early && !spec) stream_graph_fn<BLOCK, AP, SC, FL>(p, out, l, Gv, n0, tid, tid, BLOCK, true, any_mask);
+        if (spec) {
+            if (any_mask && !(abl & 4)) {
+                for (int q = tid; q < Gv * EE; q += BLOCK) {
+                    const int gg = fdiv(q, EE, p.m_EE), rc = q - gg * EE;
+                    if (!l.flags[gg * 4 + 2]) continue;
+                    const int r = fdiv(rc, E, p.m_E), cc = rc - r * E;
+                    if (l.moff[gg * E + r] | l.moff[gg * E + cc]) l.M[(size_t)gg * EE4 + rc] = 0.0f;
+                }
+            }
+            __syncthreads();
+        }
+        if (step) {
+            if (!spec || tid < 64) {
+                // ---- sections 3+4 (obs, reward, info, write-back). In specialised tiles only wave 0 gets here and the
+                // block barrier between the two sections is replaced by wave-local ordering.
+                const bool block_sync = !spec;
+                // ---- 3. obs, reward, done (ego i sees agent k done iff s_old[k] || (new[k] && k < i))
+                rew = 0;
+                if (ag) {
+                    {   // staged info counters (LDS reads: unaffected by the HBM write drain that has started)
+                        const int* ci = l.cnt + (size_t)(g * A + i) * 9;
+                        trq = ci[0]; dtg = ci[1]; dleft = ci[2]; greached = ci[3]; nac = ci[4]; noc = ci[5]; sv = ci[6]; sic = ci[7]; conf = ci[8];
+                        gmt = l.cntd[(size_t)(g * A + i) * 2]; if (rotinv) pproj = l.cntd[(size_t)(g * A + i) * 2 + 1];
+                        dsp0 = l.cntd[(size_t)G * A * 2 + g];
+                    }
+                    const double px = v.ex[i], py = v.ey[i];
+                    const double* row = v.Dm + (size_t)i * E;
+                    if (rotfam) write_obs_rot<AP, SC>(p, v, i, ph1); else write_obs<AP, SC>(p, v, i, v.vox[i], v.voy[i], ph1);
+                    STAMP(13);
+                    // collision block (…_july.py:1117-1124) and info_callback's collision count (:780-786) in one sweep
+                    int ncol_r = 0, ncol_i = 0;
+                    const bool me_old = v.s_old[i] != 0, me_new = v.newf[i] != 0;
+                    if (AP) {                                                  // all LDS reads of the sweep first, then the arithmetic
+                        double rv[AP ? AP : 1]; int so[AP ? AP : 1], nf[AP ? AP : 1];
+        #pragma unroll
+                        for (int a = 0; a < AP; ++a) { const int ac = a < A ? a : 0; rv[a] = row[ac]; so[a] = v.s_old[ac]; nf[a] = v.newf[ac]; }
+                        __builtin_amdgcn_sched_barrier(0);
+        #pragma unroll
+                        for (int a = 0; a < AP; ++a) {
+                            const bool close = a < A && rv[a] < c.sep_dist && a != i;
+                            ncol_r += (close && !so[a] && !(nf[a] && a < i)) ? 1 : 0;
+                            ncol_i += (close && !so[a] && !(nf[a] && a <= i)) ? 1 : 0;
+                        }
+                    } else {
+                        for (int a = 0; a < A; ++a) {
+                            const bool close = row[a] < c.sep_dist && a != i;
+                            const int so = v.s_old[a], nf = v.newf[a];
+                            ncol_r += (close && !so && !(nf && a < i)) ? 1 : 0;
+                            ncol_i += (close && !so && !(nf && a <= i)) ? 1 : 0;
                         }
                     }
-                    double herr = 0;
-                    if (two || three) herr = fabs(heading_error_signed(v.tube, v.s2[i]));           // pre-reward heading
-                    if (cp == 0) {
-                        const double de = entrance_gate_distance(ts, ty, hw);
-                        rew -= de;
-                        if ((two || three) && de < c.world_size * 0.1) rew -= herr * c.formation_rew * 0.5;
-                    } else if (cp == 1) {
-                        double hx, hy; sincos(v.s2[i], &hy, &hx);
-                        int front = -1, back = -1; double fproj = 0, bproj = 0;
-                        for (int k = 0; k < A; ++k) {
-                            if (k == i) continue;
-                            const double pj = (v.ex[k] - px) * hx + (v.ey[k] - py) * hy;
-                            if (pj > 0) { if (front < 0 || pj < fproj) { front = k; fproj = pj; } }
-                            else { if (back < 0 || pj > bproj) { back = k; bproj = pj; } }
+                    if (me_old) { ncol_r = 0; }
+                    if (me_old || me_new) ncol_i = 0;
+                    // reward term per contact: 4 x collision_rew (…_july.py:1117-1124, rot_inv.py:1134-1139); three_phase_graph.py:965-970: 1 x;
+                    // two_phase_graph.py: none (block commented out)
+                    if (three) { for (int q = 0; q < ncol_r; ++q) rew -= c.collision_rew; }
+                    else if (!two) for (int q = 0; q < ncol_r; ++q) rew -= c.collision_rew * 4;
+                    nac += ncol_i;
+                    STAMP(14);
+                    const bool obst_hit = obstacle_collision_ego(p, v, i);
+                    if (obst_hit) { if (!two && !three) rew -= c.collision_rew * 3; noc += 1; }
+                    double serr = 0;
+                    if (july) {
+                        const double tdx = v.tube[T_EXX] - v.tube[T_ENTX], tdy = v.tube[T_EXY] - v.tube[T_ENTY];
+                        const double tlen = sqrt(tdx * tdx + tdy * tdy);
+                        if (cp == 2 && cp > prevA + 1) rew -= c.goal_rew * 3;
+                        const double ux = tdx / tlen, uy = tdy / tlen;
+                        const double qx = px - v.tube[T_ENTX], qy = py - v.tube[T_ENTY];
+                        const double proj = qx * ux + qy * uy;
+                        if (cp == prevA + 1 && phase_reached == cp - 1) {
+                            if (cp == 1) {
+                                const double edist = norm2(qx - proj * tdx, qy - proj * tdy);   // un-normalised (:1154)
+                                if (0 <= proj && proj < 0.1 * tlen && edist < 0.2 * tlen) rew += c.goal_rew * 3;
+                            } else if (cp == 2) rew += c.goal_rew * 3;
                         }
-                        if (front >= 0) { const double df = row[front] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
-                        if (back >= 0) { const double df = row[back] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
-                        if (serr > 0) sv += 1;
-                        rew -= serr * c.formation_rew;
-                        rew -= exit_gate_distance(ts, ty, Lt, hw);
-                        if (rotinv) {
-                            const double tdx = v.tube[T_EXX] - v.tube[T_ENTX], tdy = v.tube[T_EXY] - v.tube[T_ENTY];
-                            const double tlen = sqrt(tdx * tdx + tdy * tdy);
-                            const double proj = (px - v.tube[T_ENTX]) * (tdx / tlen) + (py - v.tube[T_ENTY]) * (tdy / tlen);
-                            const double gain = c.goal_rew / (c.world_size * 0.8 * 10);         // :522
-                            const double dproj = proj - pproj;
-                            rew += gain * (dproj > -0.05 ? dproj : -0.05);
-                            pproj = (double)(float)proj;                                       // float32 array (:374)
-                        } else rew -= herr * c.formation_rew * 0.1;
-                        sic += 1;
-                    } else if (rotinv && cp == 2 && phase_reached == 0) cp = 0;
-                    else if (cp == 2 && !two) {
+                        if (cp == 0) rew -= norm2(v.tube[T_ENTX] - px, v.tube[T_ENTY] - py);
+                        else if (cp == 1) {
+                            double hx, hy; sincos(v.s2[i], &hy, &hx);
+                            int front = -1, back = -1; double fproj = 0, bproj = 0;
+                            for (int k = 0; k < A; ++k) {                       // 1136-1143, first wins ties
+                                if (k == i) continue;
+                                const double pj = (v.ex[k] - px) * hx + (v.ey[k] - py) * hy;
+                                if (pj > 0) { if (front < 0 || pj < fproj) { front = k; fproj = pj; } }
+                                else { if (back < 0 || pj > bproj) { back = k; bproj = pj; } }
+                            }
+                            if (front >= 0) { const double df = row[front] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
+                            if (back >= 0) { const double df = row[back] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
+                            if (serr > 0) sv += 1;
+                            rew -= serr * c.formation_rew;
+                            rew -= norm2(v.tube[T_EXX] - px, v.tube[T_EXY] - py);
+                            sic += 1;
+                        } else if (cp == 2 && phase_reached == 0) cp = 0;
+                        else {
+                            if (dgoal < c.goal_thresh) { if (me_new) rew += c.goal_rew * 5; }
+                            else rew -= dgoal;
+                        }
+                        if (phase_reached == 1 && cp == 0) conf += 1;
+                        if (cp > phase_reached) phase_reached = cp;
+                        if (cp < prevA) rew -= c.collision_rew * 3;
+                        if (cp < phase_reached) rew -= c.collision_rew;
+                        prev_phase = cp;
+                    } else if (rotfam) {
+                        // Scenario.reward, rot_inv.py:1122-1338; two_phase_graph.py:955-1142; three_phase_graph.py:957-1160
+                        const double Lt = v.tube[T_L], hw = v.tube[T_HALFW];
+                        double ts, ty; tube_sy(v.tube, px, py, ts, ty);
+                        if (cp == 2 && cp > prev_phase + 1) rew -= c.goal_rew;
+                        if (cp == prev_phase + 1 && phase_reached == cp - 1) {
+                            if (cp == 1 && in_entrance_gate(ts, ty, Lt, hw) && cooldown == 0) {
+                                rew += c.goal_rew;
+                                // rot_inv: episode_length/10 as a float into an int32 array (:1200, :228); phase graphs: episode_length
+                                cooldown = (two || three) ? c.episode_length : (int)((double)c.episode_length / 10);
+                                phase_reached = 1;
+                            } else if (cp == 2) {
+                                rew += c.goal_rew; phase_reached = 2;
+                                if (two && me_new) rew += c.goal_rew * 5;                               // finished at the exit gate (:1040-1044)
+                            }
+                        }
+                        double herr = 0;
+                        if (two || three) herr = fabs(heading_error_signed(v.tube, v.s2[i]));           // pre-reward heading
+                        if (cp == 0) {
+                            const double de = entrance_gate_distance(ts, ty, hw);
+                            rew -= de;
+                            if ((two || three) && de < c.world_size * 0.1) rew -= herr * c.formation_rew * 0.5;
+                        } else if (cp == 1) {
+                            double hx, hy; sincos(v.s2[i], &hy, &hx);
+                            int front = -1, back = -1; double fproj = 0, bproj = 0;
+                            for (int k = 0; k < A; ++k) {
+                                if (k == i) continue;
+                                const double pj = (v.ex[k] - px) * hx + (v.ey[k] - py) * hy;
+                                if (pj > 0) { if (front < 0 || pj < fproj) { front = k; fproj = pj; } }
+                                else { if (back < 0 || pj > bproj) { back = k; bproj = pj; } }
+                            }
+                            if (front >= 0) { const double df = row[front] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
+                            if (back >= 0) { const double df = row[back] - c.sep_dist; serr += df < 0 ? fabs(df) : 0; }
+                            if (serr > 0) sv += 1;
+                            rew -= serr * c.formation_rew;
+                            rew -= exit_gate_distance(ts, ty, Lt, hw);
+                            if (rotinv) {
+                                const double tdx = v.tube[T_EXX] - v.tube[T_ENTX], tdy = v.tube[T_EXY] - v.tube[T_ENTY];
+                                const double tlen = sqrt(tdx * tdx + tdy * tdy);
+                                const double proj = (px - v.tube[T_ENTX]) * (tdx / tlen) + (py - v.tube[T_ENTY]) * (tdy / tlen);
+                                const double gain = c.goal_rew / (c.world_size * 0.8 * 10);         // :522
+                                const double dproj = proj - pproj;
+                                rew += gain * (dproj > -0.05 ? dproj : -0.05);
+                                pproj = (double)(float)proj;                                       // float32 array (:374)
+                            } else rew -= herr * c.formation_rew * 0.1;
+                            sic += 1;
+                        } else if (rotinv && cp == 2 && phase_reached == 0) cp = 0;
+                        else if (cp == 2 && !two) {
+                            if (dgoal < c.goal_thresh) { if (me_new) rew += c.goal_rew * 5; }
+                            else rew -= dgoal;
+                        }
+                        if (phase_reached == 1 && cp == 0) conf += 1;
+                        if (cp > phase_reached) phase_reached = cp;
+                        if (cp < prev_phase) rew -= c.collision_rew;
+                        if (cp < phase_reached) rew -= c.collision_rew;
+                        prev_phase = cp;
+                        if (in_tube_rect(ts, ty, Lt, hw) && cp != 1 && !(three && in_exit_gate(ts, ty, Lt, hw, 0.02))) rew -= c.collision_rew;
+                        if (ts > Lt && phase_reached < 1) rew -= c.goal_rew;
+                    } else {
                         if (dgoal < c.goal_thresh) { if (me_new) rew += c.goal_rew * 5; }
                         else rew -= dgoal;
                     }
-                    if (phase_reached == 1 && cp == 0) conf += 1;
-                    if (cp > phase_reached) phase_reached = cp;
-                    if (cp < prev_phase) rew -= c.collision_rew;
-                    if (cp < phase_reached) rew -= c.collision_rew;
-                    prev_phase = cp;
-                    if (in_tube_rect(ts, ty, Lt, hw) && cp != 1 && !(three && in_exit_gate(ts, ty, Lt, hw, 0.02))) rew -= c.collision_rew;
-                    if (ts > Lt && phase_reached < 1) rew -= c.goal_rew;
-                } else {
-                    if (dgoal < c.goal_thresh) { if (me_new) rew += c.goal_rew * 5; }
-                    else rew -= dgoal;
+                    rew = clipd(rew, -4 * c.collision_rew, c.goal_rew * 5);
+                    if (!rotfam) rew = clipd(rew, c.min_reward, c.max_reward);                      // rot_inv.py:1338 clips once
+                    v.serr[i] = two ? 0.0 : serr; v.rew[i] = rew;           // two_phase_graph.py never appends to delta_spacing
+
+                    STAMP(15);
+                    // ---- info counters that depend on own data only (…_july.py:744-773)
+                    v.dtg_o[i] = dtg; v.trq_o[i] = trq;
+                    int nearest = 0; double dmin = INF;
+                    SWEEP(q, L) { const bool ok = !AP || q < L; const double d = ok ? row[A + (ok ? q : 0)] : INF; const bool lt = d < dmin; dmin = lt ? d : dmin; nearest = lt ? q : nearest; }
+                    const double thr = c.goal_thresh;
+                    const int tnow = (int)((double)cur_step * c.dt);
+                    if (dmin < thr && (nearest != greached && greached != -1)) { greached = nearest; dleft = (int)dmin; }
+                    if (dmin < thr && trq == -1) { trq = tnow; dtg = (int)p_dist; dleft = (int)dmin; greached = nearest; }
+                    if (trq == -1) { dtg = (int)p_dist; dleft = (int)dmin; }
+                    if (dmin > thr && trq != -1) { dtg = (int)p_dist; trq = tnow; dleft = (int)dmin; }
+                    if (dmin < thr && nearest == greached) { dleft = (int)dmin; greached = nearest; }
+                    v.dtg_n[i] = dtg; v.trq_n[i] = trq;
+                    v.sv_n[i] = sv; v.sv_o[i] = sv - (serr > 0 ? 1 : 0);
                 }
-                rew = clipd(rew, -4 * c.collision_rew, c.goal_rew * 5);
-                if (!rotfam) rew = clipd(rew, c.min_reward, c.max_reward);                      // rot_inv.py:1338 clips once
-                v.serr[i] = two ? 0.0 : serr; v.rew[i] = rew;           // two_phase_graph.py never appends to delta_spacing
+                if (block_sync) __syncthreads();
+                else {                                                          // every agent lane lives in wave 0: LDS ops of one wave are
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // executed in order, the fences only pin the compiler's order
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                STAMP(6);
 
-                STAMP(15);
-                // ---- info counters that depend on own data only (…_july.py:744-773)
-                v.dtg_o[i] = dtg; v.trq_o[i] = trq;
-                int nearest = 0; double dmin = INF;
-                SWEEP(q, L) { const bool ok = !AP || q < L; const double d = ok ? row[A + (ok ? q : 0)] : INF; const bool lt = d < dmin; dmin = lt ? d : dmin; nearest = lt ? q : nearest; }
-                const double thr = c.goal_thresh;
-                const int tnow = (int)((double)cur_step * c.dt);
-                if (dmin < thr && (nearest != greached && greached != -1)) { greached = nearest; dleft = (int)dmin; }
-                if (dmin < thr && trq == -1) { trq = tnow; dtg = (int)p_dist; dleft = (int)dmin; greached = nearest; }
-                if (trq == -1) { dtg = (int)p_dist; dleft = (int)dmin; }
-                if (dmin > thr && trq != -1) { dtg = (int)p_dist; trq = tnow; dleft = (int)dmin; }
-                if (dmin < thr && nearest == greached) { dleft = (int)dmin; greached = nearest; }
-                v.dtg_n[i] = dtg; v.trq_n[i] = trq;
-                v.sv_n[i] = sv; v.sv_o[i] = sv - (serr > 0 ? 1 : 0);
-            }
-            if (block_sync) __syncthreads();
-            else {                                                          // every agent lane lives in wave 0: LDS ops of one wave are
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // executed in order, the fences only pin the compiler's order
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-            STAMP(6);
-
-            // ---- 4. info (sequential view: agents j<=i already updated, j>i not yet), outputs, write-back
-            if (ag) {
-                double rsum = 0;
-                if (c.collaborative) for (int a = 0; a < A; ++a) rsum += v.rew[a];
-                if (p.o.reward) p.o.reward[na] = (float)(c.collaborative ? rsum : rew);
-                if (p.o.done) p.o.done[na] = done ? 1 : 0;
-                if (p.o.info) {
-                    // the counters are small integers: their sums and sums of squares are exact in fp64 in any order
-                    double sd = 0, st = 0, sdd = 0, stt = 0; int ssv = 0;
-                    SWEEP(a, A) {
-                        const bool ok = !AP || a < A;
-                        const int ac = ok ? a : 0;
-                        const bool nw = ac <= i;
-                        const int dn = v.dtg_n[ac], d_o = v.dtg_o[ac], tn = v.trq_n[ac], to = v.trq_o[ac], svn = v.sv_n[ac], svo = v.sv_o[ac];
-                        const double dd = ok ? (double)(nw ? dn : d_o) : 0.0, tt = ok ? (double)(nw ? tn : to) : 0.0;
-                        sd += dd; st += tt; sdd += dd * dd; stt += tt * tt;
-                        ssv += ok ? (nw ? svn : svo) : 0;
+                // ---- 4. info (sequential view: agents j<=i already updated, j>i not yet), outputs, write-back
+                if (ag) {
+                    double rsum = 0;
+                    if (c.collaborative) for (int a = 0; a < A; ++a) rsum += v.rew[a];
+                    if (out.reward) out.reward[na] = (float)(c.collaborative ? rsum : rew);
+                    if (out.done) out.done[na] = done ? 1 : 0;
+                    if (ROLL) {                                                 // GraphReplayBuffer.insert's mask rules (graph_buffer.py:223-251; graph_mpe_runner.py:85-90, 395-405)
+                        if (p.masks) p.masks[(size_t)slot * p.st_mask + na] = done ? 0.0f : 1.0f;
+                        if (p.active) p.active[(size_t)slot * p.st_mask + na] = (done && !all_done) ? 0.0f : 1.0f;
                     }
-                    double dsp = dsp0;
-                    if (july || rotfam) for (int a = 0; a <= i; ++a) dsp += v.serr[a];   // same order as the list append (:1180)
-                    const double dm = sd / A, tm = st / A;
-                    // population variance = (A*sum(x^2) - sum(x)^2) / A^2, numerator exact
-                    const double dvn = (double)A * sdd - sd * sd, tvn = (double)A * stt - st * st;
-                    const double ds = sqrt(dvn) / A, ts = sqrt(tvn) / A;
-                    float* o = p.o.info + na * GMPE_INFO_KEYS;
-                    o[0] = (float)rew; o[1] = (float)dleft; o[2] = (float)trq; o[3] = (float)nac; o[4] = (float)noc;
-                    o[5] = (float)dm; o[6] = (float)ds; o[7] = (float)(dm / (ds + 0.0001)); o[8] = (float)dtg;
-                    o[9] = (float)trq; o[10] = (float)tm; o[11] = (float)ts; o[12] = (float)(tm / (ts + 0.0001));
-                    o[13] = (float)((double)conf / c.episode_length);
-                    o[14] = (float)(dsp / (ssv != 0 ? (double)ssv : 1.0));
-                    o[15] = (float)((double)sv / (sic != 0 ? sic : 1));
-                    o[16] = (float)gmt;
-                    o[17] = (float)phase_reached;
-                }
-                if (!all_done) {                                            // persist the stepped state
-                    if (i == 0) {
+                    if (out.info) {
+                        // the counters are small integers: their sums and sums of squares are exact in fp64 in any order
+                        double sd = 0, st = 0, sdd = 0, stt = 0; int ssv = 0;
+                        SWEEP(a, A) {
+                            const bool ok = !AP || a < A;
+                            const int ac = ok ? a : 0;
+                            const bool nw = ac <= i;
+                            const int dn = v.dtg_n[ac], d_o = v.dtg_o[ac], tn = v.trq_n[ac], to = v.trq_o[ac], svn = v.sv_n[ac], svo = v.sv_o[ac];
+                            const double dd = ok ? (double)(nw ? dn : d_o) : 0.0, tt = ok ? (double)(nw ? tn : to) : 0.0;
+                            sd += dd; st += tt; sdd += dd * dd; stt += tt * tt;
+                            ssv += ok ? (nw ? svn : svo) : 0;
+                        }
                         double dsp = dsp0;
-                        if (july || rotfam) for (int a = 0; a < A; ++a) dsp += v.serr[a];
-                        p.s.delta_spacing[n] = dsp;
-                        p.s.rng_ctr[n] = ctr0 + v.flags[1];
-                        p.s.current_step[n] = cur_step;
+                        if (july || rotfam) for (int a = 0; a <= i; ++a) dsp += v.serr[a];   // same order as the list append (:1180)
+                        const double dm = sd / A, tm = st / A;
+                        // population variance = (A*sum(x^2) - sum(x)^2) / A^2, numerator exact
+                        const double dvn = (double)A * sdd - sd * sd, tvn = (double)A * stt - st * st;
+                        const double ds = sqrt(dvn) / A, ts = sqrt(tvn) / A;
+                        float* o = out.info + na * GMPE_INFO_KEYS;
+                        o[0] = (float)rew; o[1] = (float)dleft; o[2] = (float)trq; o[3] = (float)nac; o[4] = (float)noc;
+                        o[5] = (float)dm; o[6] = (float)ds; o[7] = (float)(dm / (ds + 0.0001)); o[8] = (float)dtg;
+                        o[9] = (float)trq; o[10] = (float)tm; o[11] = (float)ts; o[12] = (float)(tm / (ts + 0.0001));
+                        o[13] = (float)((double)conf / c.episode_length);
+                        o[14] = (float)(dsp / (ssv != 0 ? (double)ssv : 1.0));
+                        o[15] = (float)((double)sv / (sic != 0 ? sic : 1));
+                        o[16] = (float)gmt;
+                        o[17] = (float)phase_reached;
                     }
+                    if (ROLL && !all_done && kk + 1 < K) {                      // rollout: carry the counters in their LDS staging slots
+                        int* ci = l.cnt + (size_t)(g * A + i) * 9;
+                        ci[0] = trq; ci[1] = dtg; ci[2] = dleft; ci[3] = greached; ci[4] = nac; ci[5] = noc; ci[6] = sv; ci[7] = sic; ci[8] = conf;
+                        if (rotinv) l.cntd[(size_t)(g * A + i) * 2 + 1] = pproj;
+                        if (i == 0) {
+                            double dsp = dsp0;
+                            if (july || rotfam) for (int a = 0; a < A; ++a) dsp += v.serr[a];
+                            l.cntd[(size_t)G * A * 2 + g] = dsp;                // read by every lane of the env at the top of section 3: same wave, program order
+                        }
+                    } else if (!all_done) {                                     // persist the stepped state
+                        if (i == 0) {
+                            double dsp = dsp0;
+                            if (july || rotfam) for (int a = 0; a < A; ++a) dsp += v.serr[a];
+                            p.s.delta_spacing[n] = dsp;
+                            p.s.rng_ctr[n] = ctr0 + v.flags[1];
+                            p.s.current_step[n] = cur_step;
+                        }
+                        p.s.x[na] = v.ex[i]; p.s.y[na] = v.ey[i]; p.s.s2[na] = v.n2[i]; p.s.s3[na] = v.n3[i];
+                        p.s.status[na] = (uint8_t)(v.s_old[i] || v.newf[i]);
+                        p.s.prev_phase[na] = prev_phase; p.s.phase_reached[na] = phase_reached; p.s.cooldown[na] = cooldown;
+                        p.s.goal_tracker[na] = v.gt[i]; p.s.p_dist[na] = p_dist; p.s.time[na] = tim;
+                        p.s.times_required[na] = trq; p.s.dists_to_goal[na] = dtg; p.s.dist_left[na] = dleft;
+                        p.s.goal_reached[na] = greached; p.s.n_agent_coll[na] = nac; p.s.n_obst_coll[na] = noc;
+                        p.s.spacing_viol[na] = sv; p.s.steps_in_corr[na] = sic; p.s.conformance[na] = conf;
+                        if (rotinv) p.s.prev_proj[na] = pproj;
+                    }
+                }
+                STAMP(7);
+                if (spec) {                                                 // wave-local: the rows were written by this wave's own lanes
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (out.obs) {
+                        float* dst = out.obs + (size_t)n0 * A * D;
+                        const int AD = A * D;
+                        for (int q = tid; q < Gv * AD; q += 64) { const int gg = fdiv(q, AD, p.m_AD); if (l.flags[gg * 4 + 3]) dst[q] = l.obs[(size_t)gg * AD4 + (q - gg * AD)]; }
+                    }
+                    if (out.agent_id) for (int q = tid; q < Gv * A; q += 64) { const int gg = fdiv(q, A, p.m_A); if (l.flags[gg * 4 + 3]) out.agent_id[(size_t)n0 * A + q] = q - gg * A; }
+                }
+            }
+            else stream_graph_fn<BLOCK, AP, SC, FL>(p, out, l, Gv, n0, tid, tid - 64, BLOCK - 64, false, any_mask);
+            __syncthreads();
+        }
+        {
+            // ---- 5. reset (explicit, or the worker's auto-reset when every agent of the env is done)
+            if (any_reset) {
+                const bool mine = ag && v.flags[0];
+                if (mine && i == 0) {                                             // one lane per resetting env
+                    int64_t ctr = ctr0 + (step ? v.flags[1] : 0);                // this step's heading re-draws come first
+                    reset_world_serial<SC>(p, v, n, ctr, err);
+                    if (ROLL) reinterpret_cast<long long*>(l.cntd + (size_t)G * A * 2 + G)[g] = ctr;
+                    p.s.rng_ctr[n] = ctr;
+                    p.s.current_step[n] = 0;
+                    p.s.delta_spacing[n] = 0.0;
+                    v.flags[2] = 0;
+                }
+                __syncthreads();
+                if (mine) {
+                    v.s2[i] = v.n2[i]; v.s3[i] = v.n3[i];
+                    double vx, vy; vel_of<SC>(v.n2[i], v.n3[i], vx, vy);
+                    v.vox[i] = v.vnx[i] = vx; v.voy[i] = v.vny[i] = vy;
+                    v.s_old[i] = 0; v.newf[i] = 0; v.gt[i] = -1; v.moff[i] = 0; v.moff[A + i] = 0;
+                    int prevA = prev_phase, ph = 0;
+                    if (july) ph = phase_eval(v.tube, v.ex[i], v.ey[i], prev_phase, prevA);   // reset-time observation (:1447)
+                    prev_phase = prevA;
+                    if (rotfam) { ph = phase_eval_rot<PV>(v.tube, v.ex[i], v.ey[i], prev_phase, 0); double sn_, cn_; sincos(v.n2[i], &sn_, &cn_); v.cn[i] = cn_; v.sn[i] = sn_; p.s.prev_proj[na] = 0.0; }
+                    const double dx = v.ex[i] - v.ex[A + i], dy = v.ey[i] - v.ey[A + i];
+                    gmt = c.max_speed > 0 ? sqrt(dx * dx + dy * dy) / c.max_speed : 0.0;
                     p.s.x[na] = v.ex[i]; p.s.y[na] = v.ey[i]; p.s.s2[na] = v.n2[i]; p.s.s3[na] = v.n3[i];
-                    p.s.status[na] = (uint8_t)(v.s_old[i] || v.newf[i]);
-                    p.s.prev_phase[na] = prev_phase; p.s.phase_reached[na] = phase_reached; p.s.cooldown[na] = cooldown;
-                    p.s.goal_tracker[na] = v.gt[i]; p.s.p_dist[na] = p_dist; p.s.time[na] = tim;
-                    p.s.times_required[na] = trq; p.s.dists_to_goal[na] = dtg; p.s.dist_left[na] = dleft;
-                    p.s.goal_reached[na] = greached; p.s.n_agent_coll[na] = nac; p.s.n_obst_coll[na] = noc;
-                    p.s.spacing_viol[na] = sv; p.s.steps_in_corr[na] = sic; p.s.conformance[na] = conf;
-                    if (rotinv) p.s.prev_proj[na] = pproj;
+                    p.s.status[na] = 0; p.s.prev_phase[na] = prev_phase; p.s.phase_reached[na] = 0; p.s.cooldown[na] = 0;
+                    p.s.goal_tracker[na] = -1; p.s.p_dist[na] = 0.0; p.s.time[na] = 0.0;
+                    p.s.times_required[na] = -1; p.s.dists_to_goal[na] = -1; p.s.dist_left[na] = -1;
+                    p.s.goal_reached[na] = -1; p.s.n_agent_coll[na] = 0; p.s.n_obst_coll[na] = 0;
+                    p.s.spacing_viol[na] = 0; p.s.steps_in_corr[na] = 0; p.s.conformance[na] = 0;
+                    p.s.goal_min_time[na] = gmt;
+                    ph1 = ph;
                 }
+                __syncthreads();                                                // positions of all agents final
+                distance_pass<BLOCK, (CT ? AP : 0)>(p, l, Gv, tid, true);
+                __syncthreads();
+                if (mine) { if (rotfam) write_obs_rot<AP, SC>(p, v, i, ph1); else write_obs<AP, SC>(p, v, i, v.vox[i], v.voy[i], ph1); }
+                any_mask = 0;
+                for (int gg = 0; gg < Gv; ++gg) any_mask |= l.flags[gg * 4 + 2];
             }
-            STAMP(7);
-            if (spec) {                                                 // wave-local: the rows were written by this wave's own lanes
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (p.o.obs) {
-                    float* dst = p.o.obs + (size_t)n0 * A * D;
-                    const int AD = A * D;
-                    for (int q = tid; q < Gv * AD; q += 64) { const int gg = fdiv(q, AD, p.m_AD); if (l.flags[gg * 4 + 3]) dst[q] = l.obs[(size_t)gg * AD4 + (q - gg * AD)]; }
+            STAMP(8);
+        }
+        if (ROLL && !early) {
+            // A reset iteration stores with every wave, a steady-state one with waves 1.. (graph) and wave 0 (obs): when consecutive steps
+            // share output addresses (one slot, or the slots wrap) two different waves write the same address in a row. Make the earlier
+            // step's stores complete (vmcnt(0): acknowledged by L2) in every wave before any wave issues the later ones.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+        }
+        if (!early) stream_graph_fn<BLOCK, AP, SC, FL>(p, out, l, Gv, n0, tid, tid, BLOCK, true, any_mask);
+        // ---- small outputs: obs staging rows and agent ids. In a specialised tile wave 0 has already stored them
+        // (it wrote the staging rows itself), so nobody waits behind the barrier for the streaming waves.
+        STAMP(11);
+        if (!spec) {
+            if (out.obs) {
+                float* dst = out.obs + (size_t)n0 * A * D;
+                const int AD = A * D;
+                for (int q = tid; q < Gv * AD; q += BLOCK) { const int gg = fdiv(q, AD, p.m_AD); if (l.flags[gg * 4 + 3]) dst[q] = l.obs[(size_t)gg * AD4 + (q - gg * AD)]; }
+            }
+            if (out.agent_id) for (int q = tid; q < Gv * A; q += BLOCK) { const int gg = fdiv(q, A, p.m_A); if (l.flags[gg * 4 + 3]) out.agent_id[(size_t)n0 * A + q] = q - gg * A; }   // get_id :1554
+        }
+        if (ROLL && kk + 1 < K) {
+            // ---- carry the state into the next step (what the next launch would have re-read from HBM)
+            if (!early) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (!spec || !early) __syncthreads();                               // the tail above read flags / staging rows with every thread
+            if (ag) {
+                if (all_done) {                                                 // this env was reset in this step (state already in LDS: section 5)
+                    phase_reached = 0; cooldown = 0; p_dist = 0.0; tim = 0.0; cur_step = 0;
+                    ctr0 = reinterpret_cast<const long long*>(l.cntd + (size_t)G * A * 2 + G)[g];
+                    int* ci = l.cnt + (size_t)(g * A + i) * 9;
+                    ci[0] = -1; ci[1] = -1; ci[2] = -1; ci[3] = -1; ci[4] = 0; ci[5] = 0; ci[6] = 0; ci[7] = 0; ci[8] = 0;
+                    l.cntd[(size_t)(g * A + i) * 2] = gmt; l.cntd[(size_t)(g * A + i) * 2 + 1] = 0.0;
+                    if (i == 0) l.cntd[(size_t)G * A * 2 + g] = 0.0;
+                } else {
+                    v.s2[i] = v.n2[i]; v.s3[i] = v.n3[i];
+                    v.s_old[i] = (v.s_old[i] || v.newf[i]) ? 1 : 0;
+                    ctr0 += ndraw;
                 }
-                if (p.o.agent_id) for (int q = tid; q < Gv * A; q += 64) { const int gg = fdiv(q, A, p.m_A); if (l.flags[gg * 4 + 3]) p.o.agent_id[(size_t)n0 * A + q] = q - gg * A; }
+                const int na_ = c.n_actions;
+                act_idx = act_next < 0 ? 0 : (act_next >= na_ ? na_ - 1 : act_next);
             }
-        }
-        else stream_graph_fn<BLOCK, AP, SC, FL>(p, l, Gv, n0, tid, tid - 64, BLOCK - 64, false, any_mask);
-        __syncthreads();
-    }
-    {
-        // ---- 5. reset (explicit, or the worker's auto-reset when every agent of the env is done)
-        if (any_reset) {
-            const bool mine = ag && v.flags[0];
-            if (mine && i == 0) {                                             // one lane per resetting env
-                int64_t ctr = ctr0 + (step ? v.flags[1] : 0);                // this step's heading re-draws come first
-                reset_world_serial<SC>(p, v, n, ctr, err);
-                p.s.rng_ctr[n] = ctr;
-                p.s.current_step[n] = 0;
-                p.s.delta_spacing[n] = 0.0;
-                v.flags[2] = 0;
+            for (int q = tid; q < G * E; q += BLOCK) l.moff[q] = 0;
+            if (tid < G) {
+                const bool active = n0 + tid < N;
+                l.flags[tid * 4 + 0] = 0; l.flags[tid * 4 + 1] = 0; l.flags[tid * 4 + 2] = 0; l.flags[tid * 4 + 3] = active;
             }
+            slot = slot + 1 == p.num_slots ? 0 : slot + 1;
             __syncthreads();
-            if (mine) {
-                v.s2[i] = v.n2[i]; v.s3[i] = v.n3[i];
-                double vx, vy; vel_of<SC>(v.n2[i], v.n3[i], vx, vy);
-                v.vox[i] = v.vnx[i] = vx; v.voy[i] = v.vny[i] = vy;
-                v.s_old[i] = 0; v.newf[i] = 0; v.gt[i] = -1; v.moff[i] = 0; v.moff[A + i] = 0;
-                int prevA = prev_phase, ph = 0;
-                if (july) ph = phase_eval(v.tube, v.ex[i], v.ey[i], prev_phase, prevA);   // reset-time observation (:1447)
-                prev_phase = prevA;
-                if (rotfam) { ph = phase_eval_rot<PV>(v.tube, v.ex[i], v.ey[i], prev_phase, 0); double sn_, cn_; sincos(v.n2[i], &sn_, &cn_); v.cn[i] = cn_; v.sn[i] = sn_; p.s.prev_proj[na] = 0.0; }
-                const double dx = v.ex[i] - v.ex[A + i], dy = v.ey[i] - v.ey[A + i];
-                gmt = c.max_speed > 0 ? sqrt(dx * dx + dy * dy) / c.max_speed : 0.0;
-                p.s.x[na] = v.ex[i]; p.s.y[na] = v.ey[i]; p.s.s2[na] = v.n2[i]; p.s.s3[na] = v.n3[i];
-                p.s.status[na] = 0; p.s.prev_phase[na] = prev_phase; p.s.phase_reached[na] = 0; p.s.cooldown[na] = 0;
-                p.s.goal_tracker[na] = -1; p.s.p_dist[na] = 0.0; p.s.time[na] = 0.0;
-                p.s.times_required[na] = -1; p.s.dists_to_goal[na] = -1; p.s.dist_left[na] = -1;
-                p.s.goal_reached[na] = -1; p.s.n_agent_coll[na] = 0; p.s.n_obst_coll[na] = 0;
-                p.s.spacing_viol[na] = 0; p.s.steps_in_corr[na] = 0; p.s.conformance[na] = 0;
-                p.s.goal_min_time[na] = gmt;
-                ph1 = ph;
-            }
-            __syncthreads();                                                // positions of all agents final
-            distance_pass<BLOCK, (CT ? AP : 0)>(p, l, Gv, tid, true);
-            __syncthreads();
-            if (mine) { if (rotfam) write_obs_rot<AP, SC>(p, v, i, ph1); else write_obs<AP, SC>(p, v, i, v.vox[i], v.voy[i], ph1); }
-            any_mask = 0;
-            for (int gg = 0; gg < Gv; ++gg) any_mask |= l.flags[gg * 4 + 2];
         }
-        STAMP(8);
-    }
-    if (!early) stream_graph_fn<BLOCK, AP, SC, FL>(p, l, Gv, n0, tid, tid, BLOCK, true, any_mask);
-    // ---- small outputs: obs staging rows and agent ids. In a specialised tile wave 0 has already stored them
-    // (it wrote the staging rows itself), so nobody waits behind the barrier for the streaming waves.
-    STAMP(11);
-    if (!spec) {
-        if (p.o.obs) {
-            float* dst = p.o.obs + (size_t)n0 * A * D;
-            const int AD = A * D;
-            for (int q = tid; q < Gv * AD; q += BLOCK) { const int gg = fdiv(q, AD, p.m_AD); if (l.flags[gg * 4 + 3]) dst[q] = l.obs[(size_t)gg * AD4 + (q - gg * AD)]; }
-        }
-        if (p.o.agent_id) for (int q = tid; q < Gv * A; q += BLOCK) { const int gg = fdiv(q, A, p.m_A); if (l.flags[gg * 4 + 3]) p.o.agent_id[(size_t)n0 * A + q] = q - gg * A; }   // get_id :1554
-    }
+    } while (ROLL && ++kk < K);
     if (ag && err) atomicOr(&p.s.error_flags[n], err);
     STAMP(12);
 }
@@ -1197,6 +1302,6 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (AP >
 // Host entry points of one scenario variant; defined and explicitly instantiated in gmpe_sc.hip (-DGMPE_SC=k).
 template <int SC> void launch_env(int block, int ap, int fl, dim3 grid, size_t lds, hipStream_t st, const KParams& p);
 template <int SC> hipError_t set_max_lds(int lds);
-template <int SC> int max_tiles_per_cu(int block, int ap, size_t lds);   // of the steady-state (FL) instantiation where one exists
+template <int SC> int max_tiles_per_cu(int block, int ap, size_t lds, int roll);   // of the steady-state (FL = 1) instantiation where one exists; roll: of the rollout (FL = 2) one
 
 }  // namespace gmpe

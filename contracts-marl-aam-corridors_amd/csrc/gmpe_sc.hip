@@ -1,6 +1,7 @@
 // gmpe_sc.hip — one scenario variant of the fused kernel per translation unit (compiled with -DGMPE_SC=<variant>, in
 // parallel): tile shapes BLOCK in {64,128,256} x exact-size instantiations AP in {0,3,10}, plus the steady-state instantiation
-// <256, 10, SC, FL = 1> (run-time flags folded) that the C2/C3-shaped workloads run.
+// <256, 10, SC, FL = 1> (run-time flags folded) that the C2/C3-shaped workloads run, plus the rollout instantiations
+// <{64, 256}, 0, SC, FL = 2> (K steps inside one launch, gmpe_rollout_steps).
 #include "gmpe_kernel.h"
 
 #ifndef GMPE_SC
@@ -11,6 +12,11 @@ namespace gmpe {
 
 template <int SC>
 void launch_env(int block, int ap, int fl, dim3 grid, size_t lds, hipStream_t st, const KParams& p) {
+    if (fl == 2) {                                                       // persistent rollout kernel: BLOCK 64 or 256, run-time sizes (the exact-size
+        if (block == 64) hipLaunchKernelGGL((k_env<64, 0, SC, 2>), grid, dim3(64), lds, st, p);      // variants need > 168 VGPRs with the loop-carried state)
+        else hipLaunchKernelGGL((k_env<256, 0, SC, 2>), grid, dim3(256), lds, st, p);
+        return;
+    }
     if (fl && block == 256 && ap == 10) { hipLaunchKernelGGL((k_env<256, 10, SC, 1>), grid, dim3(256), lds, st, p); return; }
 #define LAUNCH_ENV(B) do { \
         if (ap == 10) hipLaunchKernelGGL((k_env<B, 10, SC, 0>), grid, dim3(B), lds, st, p); \
@@ -29,20 +35,23 @@ void launch_env(int block, int ap, int fl, dim3 grid, size_t lds, hipStream_t st
 template <int SC>
 hipError_t set_max_lds(int lds) {
 #define FN(B, P) reinterpret_cast<const void*>(&k_env<B, P, SC, 0>)
-    const void* fns[10] = {FN(64, 0), FN(64, 3), FN(64, 10), FN(128, 0), FN(128, 3), FN(128, 10), FN(256, 0), FN(256, 3), FN(256, 10),
-                           reinterpret_cast<const void*>(&k_env<256, 10, SC, 1>)};
+    const void* fns[12] = {FN(64, 0), FN(64, 3), FN(64, 10), FN(128, 0), FN(128, 3), FN(128, 10), FN(256, 0), FN(256, 3), FN(256, 10),
+                           reinterpret_cast<const void*>(&k_env<256, 10, SC, 1>),
+                           reinterpret_cast<const void*>(&k_env<64, 0, SC, 2>), reinterpret_cast<const void*>(&k_env<256, 0, SC, 2>)};
 #undef FN
     hipError_t e = hipSuccess;
-    for (int q = 0; q < 10 && e == hipSuccess; ++q) e = hipFuncSetAttribute(fns[q], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    for (int q = 0; q < 12 && e == hipSuccess; ++q) e = hipFuncSetAttribute(fns[q], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     return e;
 }
 
 // resident workgroups per CU of the instantiation launch_env would pick (registers + LDS), 0 on error
 template <int SC>
-int max_tiles_per_cu(int block, int ap, size_t lds) {
+int max_tiles_per_cu(int block, int ap, size_t lds, int roll) {
 #define FN(B, P) reinterpret_cast<const void*>(&k_env<B, P, SC, 0>)
 #define PICK(B) (ap == 10 ? FN(B, 10) : (ap == 3 ? FN(B, 3) : FN(B, 0)))
-    const void* fn = block == 64 ? PICK(64) : (block == 128 ? PICK(128) : (ap == 10 ? reinterpret_cast<const void*>(&k_env<256, 10, SC, 1>) : PICK(256)));
+    if (roll) block = block == 64 ? 64 : 256;
+    const void* fn = roll ? (block == 64 ? reinterpret_cast<const void*>(&k_env<64, 0, SC, 2>) : reinterpret_cast<const void*>(&k_env<256, 0, SC, 2>))
+                          : block == 64 ? PICK(64) : (block == 128 ? PICK(128) : (ap == 10 ? reinterpret_cast<const void*>(&k_env<256, 10, SC, 1>) : PICK(256)));
 #undef PICK
 #undef FN
     int nb = 0;
@@ -51,7 +60,7 @@ int max_tiles_per_cu(int block, int ap, size_t lds) {
 }
 
 template void launch_env<GMPE_SC>(int, int, int, dim3, size_t, hipStream_t, const KParams&);
-template int max_tiles_per_cu<GMPE_SC>(int, int, size_t);
+template int max_tiles_per_cu<GMPE_SC>(int, int, size_t, int);
 template hipError_t set_max_lds<GMPE_SC>(int);
 
 }  // namespace gmpe

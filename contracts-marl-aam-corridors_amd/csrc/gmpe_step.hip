@@ -96,6 +96,37 @@ __global__ __launch_bounds__(256) void k_masks(const uint8_t* __restrict__ done,
     if (active) active[q] = (d && !all) ? 0.0f : 1.0f;
 }
 
+// Big-E path (c4 / c5: the A ego copies of the adjacency are 89-97 % of a step's bytes): the fused kernel writes the env's single
+// E x E matrix into the handle's scratch and this kernel materialises [N,A,E,E] from it — the reference's per-agent adj arrays alias
+// ONE matrix (…_july.py:1625, 1647-1648), so the expansion is an exact broadcast. A pure streaming kernel at full
+// occupancy (no LDS, ~16 VGPRs): each lane loads one float4 of the matrix (read 1/A of the bytes written) and stores it to the A
+// copies with the nontemporal hint; a wave's store covers 1 KB contiguous, consecutive workgroups consecutive 4 KB of the same copy.
+typedef float v4f_t2 __attribute__((ext_vector_type(4)));
+template <int U>
+__global__ __launch_bounds__(256) void k_adj_expand(const float* __restrict__ src, float* __restrict__ dst, uint32_t total4, uint32_t nq, int A) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;                 // total4 < 2^32 is checked by gmpe_create
+    if (t >= total4) return;
+    const long long n = t / nq;                                          // one 32-bit division per lane, amortised over the A stores
+    const int m = (int)(t - (uint32_t)n * nq);
+    const v4f_t2 val = reinterpret_cast<const v4f_t2*>(src)[t];
+    v4f_t2* d = reinterpret_cast<v4f_t2*>(dst) + n * (long long)A * nq + m;
+    int a = 0;
+    for (; a + U <= A; a += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(val, d + (long long)(a + u) * nq);
+    }
+    for (; a < A; ++a) __builtin_nontemporal_store(val, d + (long long)a * nq);
+}
+// scalar variant for E*E % 4 != 0 (odd E)
+__global__ __launch_bounds__(256) void k_adj_expand1(const float* __restrict__ src, float* __restrict__ dst, uint32_t total, uint32_t EE, int A) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= total) return;
+    const long long n = t / EE; const int m = (int)(t - (uint32_t)n * EE);
+    const float val = src[t];
+    float* d = dst + n * (long long)A * EE + m;
+    for (int a = 0; a < A; ++a) d[(long long)a * EE] = val;
+}
+
 }  // namespace gmpe
 
 // =================================================================== host side / C ABI
@@ -117,6 +148,10 @@ struct gmpe_handle {
     int ablate = 0;
     int nt = 0;
     int spec = 0;
+    int split = 0;                   // big-E path: k_env -> compact scratch -> k_adj_expand
+    int roll = 1;                    // gmpe_step_many runs the persistent rollout kernel
+    int G_roll = 1, block_roll = 256;   // tile shape of the rollout kernel (its own register budget -> its own residency)
+    float* adj_scratch = nullptr;    // [N,E,E] (split path only)
     unsigned long long* stamps = nullptr;
     hipEvent_t region_ev[2] = {nullptr, nullptr};
     int32_t* edge_ws = nullptr;      // [cap_graphs] counts | [cap_graphs] offsets | [cap_graphs/1024+2] chunk sums
@@ -151,14 +186,14 @@ static int sc_of(const gmpe_config& c) {
         default: return c.num_walls > 0 ? SC_NAV_WALLS : SC_NAV;
     }
 }
-static int sc_dispatch_occ(int sc, int block, int ap, size_t lds) {
+static int sc_dispatch_occ(int sc, int block, int ap, size_t lds, int roll = 0) {
     switch (sc) {
-        case SC_NAV: return max_tiles_per_cu<SC_NAV>(block, ap, lds);
-        case SC_NAV_WALLS: return max_tiles_per_cu<SC_NAV_WALLS>(block, ap, lds);
-        case SC_JULY: return max_tiles_per_cu<SC_JULY>(block, ap, lds);
-        case SC_ROT: return max_tiles_per_cu<SC_ROT>(block, ap, lds);
-        case SC_TWO: return max_tiles_per_cu<SC_TWO>(block, ap, lds);
-        default: return max_tiles_per_cu<SC_THREE>(block, ap, lds);
+        case SC_NAV: return max_tiles_per_cu<SC_NAV>(block, ap, lds, roll);
+        case SC_NAV_WALLS: return max_tiles_per_cu<SC_NAV_WALLS>(block, ap, lds, roll);
+        case SC_JULY: return max_tiles_per_cu<SC_JULY>(block, ap, lds, roll);
+        case SC_ROT: return max_tiles_per_cu<SC_ROT>(block, ap, lds, roll);
+        case SC_TWO: return max_tiles_per_cu<SC_TWO>(block, ap, lds, roll);
+        default: return max_tiles_per_cu<SC_THREE>(block, ap, lds, roll);
     }
 }
 static hipError_t sc_dispatch_lds(int sc, int lds) {
@@ -310,16 +345,49 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
         uint64_t d = (uint64_t)h->A * E;
         const uint64_t cand[] = {(uint64_t)E * E, S * S, (uint64_t)h->A * (h->A + h->O), (uint64_t)h->A * h->D, 2ull * E};
         for (uint64_t x : cand) if (x > d) d = x;
-        if ((uint64_t)G * d * d >= (1ull << 32)) { gmpe_destroy(h); return fail(GMPE_ERR_UNSUPPORTED, "tile too large for the index arithmetic"); }
+        if ((uint64_t)Gmax * d * d >= (1ull << 32)) { gmpe_destroy(h); return fail(GMPE_ERR_UNSUPPORTED, "tile too large for the index arithmetic"); }
     }
     h->G = G;
-    h->ablate = getenv("GMPE_ABLATE") ? atoi(getenv("GMPE_ABLATE")) : 0;
+    {   // rollout kernel: same rule (every tile resident, from four tiles per CU upward) with ITS registers; BLOCK 256 unless the step kernel runs single-wave tiles
+        const char* env_gr = getenv("GMPE_GROLL");
+        h->block_roll = ((env_block ? atoi(env_block) : block_sel) == 64) ? 64 : 256;
+        int Gr = 0;
+        if (!env_g && !env_gr) {
+            int G0 = (int)((N + 4 * (size_t)dev_cus - 1) / (4 * (size_t)dev_cus));
+            if (G0 < 1) G0 = 1;
+            for (int g = G0; g <= Gmax && !Gr; ++g) {
+                const size_t tiles = (N + g - 1) / g;
+                const int per_cu = sc_dispatch_occ(sc_of(h->c), h->block_roll, ap_sel, lds_bytes(g, h->A, E, h->D, cfg->num_walls), 1);
+                if (per_cu > 0 && tiles <= (size_t)per_cu * dev_cus) Gr = g;
+            }
+        }
+        if (!Gr) Gr = env_gr ? atoi(env_gr) : (env_g ? G : Gmax);
+        if (Gr < 1) Gr = 1;
+        if (Gr > Gmax) Gr = Gmax;
+        h->G_roll = Gr;
+    }
+#ifdef GMPE_DIAG
+    h->ablate = getenv("GMPE_ABLATE") ? atoi(getenv("GMPE_ABLATE")) : 0;   // diagnostic build only: timing ablations (wrong results)
+#else
+    h->ablate = 0;
+#endif
     // Graph outputs per launch vs the 256 MiB Infinity Cache: small launches (C2/C3: 92 MB) are absorbed by it and run
     // faster with ordinary stores (37.0 vs 40.4 us measured); big ones (C4 6 GB, C5 9 GB) stream past it and gain ~10 %
     // from nontemporal stores (C4 1417 -> 1285 us, C5 2005 -> 1852 us).
     {
         const double out_bytes = (double)N * h->A * ((double)E * E + 8.0 * E) * 4.0;
         h->nt = getenv("GMPE_NT") ? atoi(getenv("GMPE_NT")) : (out_bytes > 192.0 * 1024 * 1024 ? 1 : 0);
+        // The same launches split the adjacency fill from the fused kernel (see k_adj_expand): c4 1290 -> ~1030 us.
+        h->split = getenv("GMPE_SPLIT") ? atoi(getenv("GMPE_SPLIT")) : (out_bytes > 192.0 * 1024 * 1024 && h->A >= 8 ? 1 : 0);
+        if ((uint64_t)N * E * E >= (1ull << 32)) h->split = 0;            // k_adj_expand indexes the compact matrix with 32 bits
+        h->roll = getenv("GMPE_ROLL") ? atoi(getenv("GMPE_ROLL")) : 1;
+        if (h->split) {
+            void* q = nullptr;
+            hipError_t e = hipMalloc(&q, (size_t)N * E * E * sizeof(float));
+            if (e != hipSuccess) { gmpe_destroy(h); return fail(GMPE_ERR_HIP, std::string("hipMalloc(adjacency scratch): ") + hipGetErrorString(e)); }
+            h->allocs.push_back(q);
+            h->adj_scratch = static_cast<float*>(q);
+        }
     }
     const size_t stream_f4 = (size_t)G * h->A * ((size_t)E * E / 4 + 2 * (size_t)E);
     h->block = env_block ? atoi(env_block) : (block_sel ? block_sel : (stream_f4 <= 2048 ? 64 : (stream_f4 <= 6144 ? 128 : 256)));
@@ -327,7 +395,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     // Multi-wave tiles specialise (wave 0: reward / info / write-back, waves 1..: graph stores). Measured with the final register
     // budgets: C2 30.2 vs 33.2 us, C4 1286 vs 1297 us, C5 shard 1901 vs 1970 us — on everywhere (GMPE_SPEC=0 turns it off).
     h->spec = getenv("GMPE_SPEC") ? atoi(getenv("GMPE_SPEC")) : 1;
-    const size_t lds = lds_bytes(h->G, h->A, E, h->D, cfg->num_walls);
+    const size_t lds = lds_bytes(h->G > h->G_roll ? h->G : h->G_roll, h->A, E, h->D, cfg->num_walls);
     if (lds > 160 * 1024) { gmpe_destroy(h); return fail(GMPE_ERR_UNSUPPORTED, "per-tile LDS exceeds 160 KiB"); }
     if (lds > 48 * 1024) {                                   // opt in to >64 KiB dynamic LDS (gfx950: 160 KiB per CU)
         const hipError_t e = sc_dispatch_lds(sc_of(h->c), (int)lds);
@@ -398,19 +466,15 @@ int gmpe_set_field(gmpe_handle* h, int field, const void* host_src, size_t bytes
     return GMPE_OK;
 }
 
-static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* onehot, const uint8_t* mask,
-                  const gmpe_outputs* out, void* stream) {
-    if (!h) return fail(GMPE_ERR_INVALID_ARG, "null handle");
-    KParams p;
+static void fill_params(const gmpe_handle* h, KParams& p, int G) {
     memset(&p, 0, sizeof p);
     p.c = h->c; p.s = h->s;
-    if (out) p.o = *out;
-    p.act = act; p.onehot = onehot; p.mask = mask; p.mode = mode;
-    p.A = h->A; p.L = h->L; p.O = h->O; p.E = h->E; p.D = h->D; p.F = h->F; p.G = h->G;
+    p.A = h->A; p.L = h->L; p.O = h->O; p.E = h->E; p.D = h->D; p.F = h->F; p.G = G;
     p.ablate = h->ablate;
     p.nt = h->nt;
     p.spec = h->spec;
     p.stamps = h->stamps;
+    p.K = 1; p.S = 1; p.num_slots = 1;
     p.m_E = magic_of(p.E); p.m_AE = magic_of(p.A * p.E); p.m_EE = magic_of(p.E * p.E); p.m_nq = magic_of(p.E * p.E / 4);
     p.m_2E = magic_of(2 * p.E); p.m_pe = magic_of(p.A * p.E * 2); p.m_AD = magic_of(p.A * p.D); p.m_A = magic_of(p.A);
     p.m_L = magic_of(p.L); p.m_O = magic_of(p.O);
@@ -418,10 +482,33 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
     p.m_AC = magic_of(p.A * (p.A + p.O)); p.m_AEE = magic_of(p.A * p.E * p.E);
     p.m_W = magic_of(p.E * (p.E - 1) / 2); p.m_Sx = magic_of((p.E & 1) ? (p.E - 1) / 2 : p.E - 1);      // distance_pass: pairs per env, inner divisor
     p.m_FW = magic_of(p.A * (p.A - 1) / 2 + p.A * p.O);
+}
+static int ap_of(const gmpe_handle* h) { return (h->A == h->L && h->O == 0 && (h->A == 10 || h->A == 3)) ? h->A : 0; }   // exact-size instantiations of the common cases (A = L, no obstacles)
+static void dispatch_env(const gmpe_handle* h, int block, int ap, int fl, hipStream_t st, const KParams& p) {
+    const size_t lds = lds_bytes(p.G, h->A, h->E, h->D, h->c.num_walls);
+    const dim3 grid((h->c.num_envs + p.G - 1) / p.G);
+    switch (sc_of(h->c)) {
+        case SC_NAV: launch_env<SC_NAV>(block, ap, fl, grid, lds, st, p); break;
+        case SC_NAV_WALLS: launch_env<SC_NAV_WALLS>(block, ap, fl, grid, lds, st, p); break;
+        case SC_JULY: launch_env<SC_JULY>(block, ap, fl, grid, lds, st, p); break;
+        case SC_ROT: launch_env<SC_ROT>(block, ap, fl, grid, lds, st, p); break;
+        case SC_TWO: launch_env<SC_TWO>(block, ap, fl, grid, lds, st, p); break;
+        default: launch_env<SC_THREE>(block, ap, fl, grid, lds, st, p); break;
+    }
+}
+
+static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* onehot, const uint8_t* mask,
+                  const gmpe_outputs* out, void* stream) {
+    if (!h) return fail(GMPE_ERR_INVALID_ARG, "null handle");
+    KParams p;
+    fill_params(h, p, h->G);
+    if (out) p.o = *out;
+    p.act = act; p.onehot = onehot; p.mask = mask; p.mode = mode;
+    // split path: the fused kernel writes the env's single matrix into the scratch, k_adj_expand makes the A copies
+    float* adj_full = nullptr;
+    if (h->split && p.o.adj && !p.o.adj_compact) { adj_full = p.o.adj; p.o.adj = h->adj_scratch; p.o.adj_compact = 1; }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t lds = lds_bytes(h->G, h->A, h->E, h->D, h->c.num_walls);
-    const dim3 grid((h->c.num_envs + h->G - 1) / h->G);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing && !h->capturing) {
         if (h->ev_used + 2 > h->ev.size()) {
@@ -430,18 +517,51 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
         e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1];
         HIPCHK(hipEventRecord(e0, st));
     }
-    const int ap = (h->A == h->L && h->O == 0 && (h->A == 10 || h->A == 3)) ? h->A : 0;   // exact-size instantiations of the common cases (A = L, no obstacles)
     const int fl = (mode == MODE_STEP && !h->nt && !h->ablate && h->spec) ? 1 : 0;   // steady-state instantiation (flags folded)
-    switch (sc_of(h->c)) {
-        case SC_NAV: launch_env<SC_NAV>(h->block, ap, fl, grid, lds, st, p); break;
-        case SC_NAV_WALLS: launch_env<SC_NAV_WALLS>(h->block, ap, fl, grid, lds, st, p); break;
-        case SC_JULY: launch_env<SC_JULY>(h->block, ap, fl, grid, lds, st, p); break;
-        case SC_ROT: launch_env<SC_ROT>(h->block, ap, fl, grid, lds, st, p); break;
-        case SC_TWO: launch_env<SC_TWO>(h->block, ap, fl, grid, lds, st, p); break;
-        default: launch_env<SC_THREE>(h->block, ap, fl, grid, lds, st, p); break;
+    dispatch_env(h, h->block, ap_of(h), fl, st, p);
+    if (adj_full) {
+        const uint32_t EE = (uint32_t)h->E * h->E, N = (uint32_t)h->c.num_envs;
+        if ((EE & 3) == 0) {
+            const uint32_t total4 = N * (EE / 4);
+            hipLaunchKernelGGL((k_adj_expand<4>), dim3((total4 + 255) / 256), dim3(256), 0, st, h->adj_scratch, adj_full, total4, EE / 4, h->A);
+        } else {
+            const uint32_t total = N * EE;
+            hipLaunchKernelGGL(k_adj_expand1, dim3((total + 255) / 256), dim3(256), 0, st, h->adj_scratch, adj_full, total, EE, h->A);
+        }
     }
     HIPCHK(hipGetLastError());
     if (h->timing && !h->capturing) { HIPCHK(hipEventRecord(e1, st)); h->ev_used += 2; }
+    return GMPE_OK;
+}
+
+int gmpe_rollout_steps(gmpe_handle* h, const int32_t* actions_dev, const gmpe_rollout* r, const gmpe_outputs* slot0, void* stream) {
+    if (!h || !actions_dev || !r) return fail(GMPE_ERR_INVALID_ARG, "gmpe_rollout_steps: null argument");
+    if (r->num_steps < 1 || r->num_action_sets < 1 || r->num_slots < 1 || r->first_slot < 0 || r->first_slot >= r->num_slots)
+        return fail(GMPE_ERR_INVALID_ARG, "gmpe_rollout_steps: bad step / slot counts");
+    if (h->split) return fail(GMPE_ERR_UNSUPPORTED, "gmpe_rollout_steps: this handle runs the split big-E path (use gmpe_step_many)");
+    KParams p;
+    fill_params(h, p, h->G_roll);
+    if (slot0) p.o = *slot0;
+    p.act = actions_dev; p.mode = MODE_STEP;
+    p.K = r->num_steps; p.S = r->num_action_sets; p.num_slots = r->num_slots; p.first_slot = r->first_slot;
+    p.st_obs = r->stride_obs; p.st_id = r->stride_agent_id; p.st_node = r->stride_node_obs; p.st_adj = r->stride_adj;
+    p.st_rew = r->stride_reward; p.st_done = r->stride_done; p.st_info = r->stride_info; p.st_mask = r->stride_masks;
+    p.masks = r->masks; p.active = r->active_masks;
+    HIPCHK(hipSetDevice(h->device));
+    dispatch_env(h, h->block_roll, ap_of(h), 2, static_cast<hipStream_t>(stream), p);
+    HIPCHK(hipGetLastError());
+    return GMPE_OK;
+}
+
+int gmpe_get_tuning(const gmpe_handle* h, gmpe_tuning* t) {
+    if (!h || !t) return fail(GMPE_ERR_INVALID_ARG, "gmpe_get_tuning: null argument");
+    memset(t, 0, sizeof *t);
+    t->G = h->G; t->block = h->block; t->nt = h->nt; t->spec = h->spec; t->split = h->split; t->roll = h->roll; t->ap = ap_of(h);
+    t->lds_bytes = (int32_t)lds_bytes(h->G, h->A, h->E, h->D, h->c.num_walls);
+    t->G_roll = h->G_roll; t->block_roll = h->block_roll;
+#ifdef GMPE_DIAG
+    t->diag_build = 1;
+#endif
     return GMPE_OK;
 }
 
@@ -492,6 +612,17 @@ int gmpe_step_many_prepare(gmpe_handle* h, const int32_t* actions_dev, int32_t n
 int gmpe_step_many(gmpe_handle* h, const int32_t* actions_dev, int32_t num_steps, int32_t num_action_sets,
                    const gmpe_outputs* out, void* stream) {
     if (!h || !actions_dev || num_steps < 0 || num_action_sets < 1) return fail(GMPE_ERR_INVALID_ARG, "gmpe_step_many: bad arguments");
+    if (num_steps == 0) return GMPE_OK;
+    if (h->roll && !h->split && !h->timing && !h->nt && !h->ablate) {        // one launch: the persistent rollout kernel (same results as the launch loop)
+        gmpe_rollout r; memset(&r, 0, sizeof r);
+        r.num_steps = num_steps; r.num_action_sets = num_action_sets; r.num_slots = 1;
+        return gmpe_rollout_steps(h, actions_dev, &r, out, stream);
+    }
+    return gmpe_step_many_launches(h, actions_dev, num_steps, num_action_sets, out, stream);
+}
+int gmpe_step_many_launches(gmpe_handle* h, const int32_t* actions_dev, int32_t num_steps, int32_t num_action_sets,
+                            const gmpe_outputs* out, void* stream) {
+    if (!h || !actions_dev || num_steps < 0 || num_action_sets < 1) return fail(GMPE_ERR_INVALID_ARG, "gmpe_step_many_launches: bad arguments");
     if (!h->timing) {                                             // per-launch event pairs need individual launches
         gmpe_outputs o; memset(&o, 0, sizeof o); if (out) o = *out;
         const int q = find_graph(h, actions_dev, num_steps, num_action_sets, o);

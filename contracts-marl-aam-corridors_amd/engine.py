@@ -113,12 +113,42 @@ class GmpeEngine(object):
                                                    C.byref(self._o)), "gmpe_step_many_prepare")
 
     def step_many(self, action_sets, num_steps):
-        """Open-loop rollout: `num_steps` steps enqueued by one C call; step k uses action_sets[k % len]
-        (int32 device tensor [S, N, A]). Returns the outputs of the LAST step."""
+        """Open-loop rollout: `num_steps` steps enqueued by one C call — one launch of the persistent rollout kernel unless the
+        handle's tuning says otherwise; step k uses action_sets[k % len] (int32 device tensor [S, N, A]). Returns the outputs of
+        the LAST step."""
         a = action_sets
         self._check_action_sets(a)
         _lib.check(self.lib.gmpe_step_many(self.h, a.data_ptr(), int(num_steps), int(a.shape[0]), C.byref(self._o),
                                            self._stream()), "gmpe_step_many")
+        return self.out
+
+    def rollout(self, action_sets, num_steps, slot0=None, num_slots=1, first_slot=0, strides=None, masks=None, active_masks=None):
+        """K steps in ONE launch (gmpe_rollout_steps, the persistent rollout kernel). Step k reads action_sets[k % S] and writes
+        output slot (first_slot + k) % num_slots: `slot0` = StepOutputs of slot 0 (default: the engine's own buffers),
+        `strides` = dict output-name -> elements between consecutive slots (default 0). Bit-identical to `num_steps` step() calls."""
+        a = action_sets
+        self._check_action_sets(a)
+        o = self._o if slot0 is None else self._pack(slot0)
+        st = strides or {}
+        r = _lib.GmpeRollout(int(num_steps), int(a.shape[0]), int(num_slots), int(first_slot),
+                             int(st.get("obs", 0)), int(st.get("agent_id", 0)), int(st.get("node_obs", 0)), int(st.get("adj", 0)),
+                             int(st.get("reward", 0)), int(st.get("done", 0)), int(st.get("info", 0)), int(st.get("masks", 0)),
+                             None if masks is None else masks.data_ptr(), None if active_masks is None else active_masks.data_ptr())
+        _lib.check(self.lib.gmpe_rollout_steps(self.h, a.data_ptr(), C.byref(r), C.byref(o), self._stream()), "gmpe_rollout_steps")
+        return self.out
+
+    def tuning(self):
+        """What gmpe_create chose (tile shape, store flavour, split / rollout paths) as a dict."""
+        t = _lib.GmpeTuning()
+        _lib.check(self.lib.gmpe_get_tuning(self.h, C.byref(t)), "gmpe_get_tuning")
+        return {k: int(getattr(t, k)) for k, _ in _lib.GmpeTuning._fields_ if k != "reserved"}
+
+    def step_many_loop(self, action_sets, num_steps):
+        """step_many as one kernel launch per step (the closed-loop launch shape; replays a prepared hipGraph when there is one)."""
+        a = action_sets
+        self._check_action_sets(a)
+        _lib.check(self.lib.gmpe_step_many_launches(self.h, a.data_ptr(), int(num_steps), int(a.shape[0]), C.byref(self._o),
+                                                    self._stream()), "gmpe_step_many_launches")
         return self.out
 
     def step_onehot(self, onehot):

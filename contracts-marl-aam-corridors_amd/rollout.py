@@ -84,6 +84,30 @@ class DeviceRolloutBuffer(object):
         self.step = (t + 1) % self.T
         return self.engine.out
 
+    def collect(self, action_sets, num_steps=None):
+        """The runner's collect loop with a fixed action source (graph_mpe_runner.py:57-103: `for step in range(episode_length)`:
+        envs.step -> buffer.insert) as ONE launch of the persistent rollout kernel: step k reads action_sets[k % S] and writes slot
+        step+k+1 of every array in place, masks / active_masks included (gmpe_rollout_steps). Same results as `num_steps`
+        insert_step calls. Falls back to that loop on the split big-E path."""
+        K = self.T - self.step if num_steps is None else int(num_steps)
+        e = self.engine
+        if e.tuning()["split"]:
+            for k in range(K):
+                self.insert_step(action_sets[k % action_sets.shape[0]])
+            return e.out
+        NA = e.N * e.A
+        slot0 = StepOutputs(obs=self.obs[1], agent_id=self.agent_id[1], node_obs=self.node_obs[1], adj=self._adj[1],
+                            reward=self.rewards[0].view(e.N, e.A), done=self.dones[0], info=self.info)
+        strides = dict(obs=self.obs[0].numel(), agent_id=NA, node_obs=self.node_obs[0].numel(), adj=self._adj[0].numel(),
+                       reward=NA, done=NA, info=0, masks=NA)
+        e.rollout(action_sets, K, slot0=slot0, num_slots=self.T, first_slot=self.step, strides=strides,
+                  masks=self.masks[1], active_masks=self.active_masks[1])
+        # the engine's "current outputs" are the last slot written, as after insert_step
+        last = (self.step + K - 1) % self.T
+        self._bind(last + 1, last)
+        self.step = (self.step + K) % self.T
+        return e.out
+
     def after_update(self):
         """graph_buffer.py:253-283: the last slot becomes slot 0 of the next rollout."""
         for buf in (self.obs, self.node_obs, self._adj, self.agent_id, self.masks, self.active_masks):

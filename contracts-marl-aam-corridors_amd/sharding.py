@@ -3,11 +3,19 @@
 Envs never interact (the reference runs them in separate processes, env_wrappers.py:968-975), so
 rank g of G owns the contiguous range [g*N/G, (g+1)*N/G) and `step` needs NO communication; the
 per-env RNG streams are keyed by the GLOBAL env id, so a sharded run reproduces the unsharded one
-env by env. The only exchange is collecting the rollout slab on the learner rank(s): one RCCL
-all_gather (backend "nccl" on ROCm) of the COMPACT form — obs, node_obs, one ExE adj per env,
-reward, done — which is A-times smaller than the materialised [N,A,E,E] adjacency.
+env by env. The only exchange is collecting the rollout slab on the learner rank — what
+`GraphSubprocVecEnv.step_wait` does with `remote.recv()` from every worker process
+(onpolicy/envs/env_wrappers.py:996-1004) — as ONE RCCL gather (backend "nccl" on ROCm) of the COMPACT
+form: obs, node_obs, one ExE adj per env, reward, done. That is A-times smaller than the
+materialised [N,A,E,E] adjacency, and a gather to the learner moves 1/world of what an all_gather would:
+over xGMI (point-to-point links) the 7 peers send into the root in parallel.
+
+The engine writes its outputs straight into the slab (`engine.rebind` onto slab views): no pack copies.
+Two slabs alternate so that the gather of step k runs on RCCL's stream while step k+1 is computed.
 """
 import torch
+
+from .engine import StepOutputs
 
 
 def shard_range(n_total, world, rank):
@@ -19,69 +27,113 @@ def shard_range(n_total, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def slab_layout(n_envs, A, E, D, F=8):
-    """Offsets (in float32 elements) of the compact per-rank rollout slab."""
-    sizes = [("obs", n_envs * A * D), ("node_obs", n_envs * A * E * F), ("adj", n_envs * E * E),
-             ("reward", n_envs * A), ("done", n_envs * A)]
+_F32 = ("obs", "node_obs", "adj", "reward")
+
+
+def slab_layout(n_envs, A, E, D, F):
+    """Byte offsets of the compact per-rank rollout slab: four float32 sections (16-byte aligned) and the uint8 `done` tail.
+    F = node features per row (8; 7 in the rot_inv family) — taken from the engine's config, never assumed."""
+    sizes = [("obs", 4 * n_envs * A * D), ("node_obs", 4 * n_envs * A * E * F), ("adj", 4 * n_envs * E * E),
+             ("reward", 4 * n_envs * A), ("done", n_envs * A)]
     off, out = 0, {}
     for k, s in sizes:
         out[k] = (off, off + s)
-        off += s
+        off = (off + s + 15) // 16 * 16
     return out, off
 
 
-def pack_slab(out, slab, layout):
-    """Copy one step's outputs (device tensors) into the flat float32 slab."""
-    for k in ("obs", "node_obs", "adj", "reward"):
-        lo, hi = layout[k]
-        slab[lo:hi].copy_(getattr(out, k).reshape(-1))
-    lo, hi = layout["done"]
-    slab[lo:hi].copy_(out.done.reshape(-1).to(torch.float32))
-    return slab
+def slab_views(slab, layout, n_envs, A, E, D, F):
+    """Typed views of one rank's slab (a contiguous uint8 tensor) with the engine's output shapes."""
+    shp = {"obs": (n_envs, A, D), "node_obs": (n_envs, A, E, F), "adj": (n_envs, E, E), "reward": (n_envs, A)}
+    v = {k: slab[layout[k][0]:layout[k][1]].view(torch.float32).view(shp[k]) for k in _F32}
+    v["done"] = slab[layout["done"][0]:layout["done"][1]].view(n_envs, A)
+    return v
 
 
-def unpack_gathered(gathered, world, n_envs, A, E, D, F=8):
-    """gathered: [world, slab_len] -> dict of global arrays in env order (rank-major)."""
-    layout, _ = slab_layout(n_envs, A, E, D, F)
-    g = gathered.reshape(world, -1)
-    view = lambda k, shp: g[:, layout[k][0]:layout[k][1]].reshape((world * n_envs,) + shp)
-    return {"obs": view("obs", (A, D)), "node_obs": view("node_obs", (A, E, F)), "adj": view("adj", (E, E)),
-            "reward": view("reward", (A,)), "done": view("done", (A,)) > 0.5}
+def unpack_gathered(gathered, world, n_envs, A, E, D, F):
+    """gathered: uint8 [world, slab_bytes] -> dict of global arrays in env order (rank-major). The float sections are
+    returned per rank and concatenated (a strided byte view cannot be re-typed in place)."""
+    layout, nbytes = slab_layout(n_envs, A, E, D, F)
+    g = gathered.reshape(world, nbytes)
+    per = [slab_views(g[r], layout, n_envs, A, E, D, F) for r in range(world)]
+    out = {k: torch.cat([p[k] for p in per], dim=0) for k in _F32}
+    out["done"] = torch.cat([p["done"] for p in per], dim=0) != 0
+    return out
 
 
 class RolloutGather(object):
-    """step + all_gather of the compact slab. Equal shard sizes per rank (all_gather_into_tensor)."""
+    """step + gather of the compact slab to the learner rank `dst` (mode="gather", default) or to every rank
+    (mode="all_gather"). Every rank must hold the same number of envs (checked at construction). The engine must write the
+    compact adjacency (`GmpeEngine(..., adj_compact=True)`): the [N,A,E,E] form is a broadcast view the learner makes for free."""
 
-    def __init__(self, engine, world, group=None):
+    def __init__(self, engine, world, rank=None, group=None, dst=0, mode="gather"):
         import torch.distributed as dist
-        self.dist, self.group = dist, group
-        self.engine, self.world = engine, world
-        c = engine.cfg
+        if mode not in ("gather", "all_gather"):
+            raise ValueError("mode must be 'gather' or 'all_gather'")
         if not engine.adj_compact:
-            # gather the single ExE matrix: take ego 0's copy
-            self._adj_of = lambda o: o.adj[:, 0]
-        else:
-            self._adj_of = lambda o: o.adj
-        self.layout, self.slab_len = slab_layout(c.num_envs, c.num_agents, c.num_entities, c.obs_dim)
+            raise ValueError("RolloutGather needs an engine created with adj_compact=True (one ExE matrix per env is shipped)")
+        self.dist, self.group, self.mode, self.dst = dist, group, mode, int(dst)
+        self.engine, self.world = engine, int(world)
+        self.rank = dist.get_rank(group) if rank is None else int(rank)
+        c = engine.cfg
+        self.dims = (c.num_envs, c.num_agents, c.num_entities, c.obs_dim, c.node_feats)
+        self.layout, self.slab_bytes = slab_layout(*self.dims)
         dev = engine.device
-        self.slab = torch.empty(self.slab_len, dtype=torch.float32, device=dev)
-        self.gathered = torch.empty(world * self.slab_len, dtype=torch.float32, device=dev)
+        # equal shard sizes: all_gather_into_tensor / gather need one slab size
+        n = torch.tensor([c.num_envs], dtype=torch.int64, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+        lo, hi = n.clone(), n.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group); dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        if int(lo.item()) != int(hi.item()):
+            raise ValueError("RolloutGather: every rank must hold the same number of envs (got %d..%d)" % (int(lo.item()), int(hi.item())))
+        self.slabs = [torch.zeros(self.slab_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        root = self.mode == "all_gather" or self.rank == self.dst
+        self.gathered = [torch.zeros((self.world, self.slab_bytes), dtype=torch.uint8, device=dev) if root else None for _ in range(2)]
+        self._outs = []
+        for s in self.slabs:
+            v = slab_views(s, self.layout, *self.dims)
+            o = StepOutputs(obs=v["obs"], agent_id=engine.out.agent_id, node_obs=v["node_obs"], adj=v["adj"], reward=v["reward"],
+                            done=v["done"], info=engine.out.info)
+            for k in _F32 + ("done",):
+                assert getattr(o, k).numel() == getattr(engine.out, k).numel(), k      # layout vs the engine's real shapes
+            self._outs.append(o)
+        self._flip = 0
+        self._work = [None, None]
+
+    def _issue(self, b):
+        d, g = self.dist, self.group
+        if self.mode == "all_gather":
+            if d.get_backend(g) == "nccl":                       # RCCL over xGMI on the GPU node
+                return d.all_gather_into_tensor(self.gathered[b].view(-1), self.slabs[b], group=g, async_op=True)
+            return d.all_gather(list(self.gathered[b].unbind(0)), self.slabs[b], group=g, async_op=True)   # gloo (CPU rehearsal / tests)
+        dst_global = self.dst if g is None else d.get_global_rank(g, self.dst)
+        lst = list(self.gathered[b].unbind(0)) if self.rank == self.dst else None
+        return d.gather(self.slabs[b], lst, dst=dst_global, group=g, async_op=True)
+
+    def step_and_gather_async(self, action_idx):
+        """Step into the next slab and start its gather; returns the buffer index. The previous gather on that slab is waited for
+        first (depth-2 pipeline: the gather of step k overlaps the computation of step k+1)."""
+        b = self._flip
+        self._flip ^= 1
+        if self._work[b] is not None:
+            self._work[b].wait(); self._work[b] = None
+        self.engine.rebind(self._outs[b])
+        self.engine.step(action_idx)
+        self._work[b] = self._issue(b)
+        return b
+
+    def wait(self, b):
+        if self._work[b] is not None:
+            self._work[b].wait(); self._work[b] = None
+        return self.gathered[b]
 
     def step_and_gather(self, action_idx):
-        o = self.engine.step(action_idx)
+        """Blocking form: -> gathered uint8 [world, slab_bytes] on the learner rank (None elsewhere in mode="gather")."""
+        return self.wait(self.step_and_gather_async(action_idx))
 
-        class _O(object):
-            pass
-        v = _O()
-        v.obs, v.node_obs, v.adj, v.reward, v.done = o.obs, o.node_obs, self._adj_of(o), o.reward, o.done
-        pack_slab(v, self.slab, self.layout)
-        if self.dist.get_backend(self.group) == "nccl":          # RCCL over xGMI on the GPU node
-            self.dist.all_gather_into_tensor(self.gathered, self.slab, group=self.group)
-        else:                                                    # gloo (CPU rehearsal / tests)
-            parts = list(self.gathered.reshape(self.world, -1).unbind(0))
-            self.dist.all_gather(parts, self.slab, group=self.group)
-        return self.gathered
-
-    def unpack(self):
-        c = self.engine.cfg
-        return unpack_gathered(self.gathered, self.world, c.num_envs, c.num_agents, c.num_entities, c.obs_dim)
+    def unpack(self, b=None):
+        """Global arrays of the last gathered step (learner rank / every rank for all_gather)."""
+        b = (self._flip ^ 1) if b is None else b
+        g = self.wait(b)
+        if g is None:
+            return None
+        return unpack_gathered(g, self.world, *self.dims)

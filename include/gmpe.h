@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GMPE_ABI_VERSION 1
+#define GMPE_ABI_VERSION 2
 #define GMPE_NODE_FEATS 8          /* …_july.py:1771  [rel_vel2, rel_pos2, rel_goal2, occupied, type]; rot_inv: 7 (gmpe_node_feats) */
 #define GMPE_INFO_KEYS 18          /* …_july.py:806-828 + 'individual_reward' (environment.py:1048) + 'Phase_reached' (rot_inv:835) */
 #define GMPE_MAX_AGENTS 64         /* one wavefront lane per agent in the sequential-semantics pass   */
@@ -193,18 +193,45 @@ int gmpe_reset(gmpe_handle* h, const uint8_t* env_mask_dev, const gmpe_outputs* 
  * environment.py:446). */
 int gmpe_step(gmpe_handle* h, const int32_t* action_idx_dev, const gmpe_outputs* out, void* stream);
 
-/* `num_steps` consecutive steps enqueued by one call (no host round trip between launches): step k uses
+/* `num_steps` consecutive steps enqueued by one call (no host round trip between steps; one launch, see gmpe_rollout_steps): step k uses
  * action set k % num_action_sets of `actions_dev` (i32 [num_action_sets, N, A]). Outputs are overwritten
  * by every step (same buffers), exactly as a host loop over gmpe_step would. Used for open-loop rollouts
  * (random-action benchmarking, scripted policies). */
 int gmpe_step_many(gmpe_handle* h, const int32_t* actions_dev, int32_t num_steps, int32_t num_action_sets,
                    const gmpe_outputs* out, void* stream);
+/* The same steps as ONE KERNEL LAUNCH PER STEP (the closed-loop launch shape, enqueued without host round trips; replays a graph
+ * recorded by gmpe_step_many_prepare when there is one). gmpe_step_many falls back to this on the split big-E path. */
+int gmpe_step_many_launches(gmpe_handle* h, const int32_t* actions_dev, int32_t num_steps, int32_t num_action_sets,
+                            const gmpe_outputs* out, void* stream);
+
+/* Open-loop rollout in ONE launch (round 2): the K steps run inside a persistent kernel — each workgroup keeps the state of its
+ * envs in LDS / registers from step to step (no reload, one write-back at the end) and the graph stores of step k drain under
+ * step k+1's arithmetic. Results are bit-identical to K calls of gmpe_step (auto-resets included).
+ * This is what the reference's collect loop does with a fixed action source: graph_mpe_runner.py:57-103 (`for step in
+ * range(self.episode_length)`: envs.step -> GraphReplayBuffer.insert, onpolicy/utils/graph_buffer.py:168-251), minus the policy.
+ * Output placement: step k writes slot (first_slot + k) % num_slots; slot s of an output lies `stride_*` ELEMENTS after slot 0
+ * (the pointers in `slot0`). num_slots = 1 with zero strides = "every step overwrites the same buffers" (gmpe_step_many).
+ * `masks` / `active_masks` (optional, f32 [slots][N,A], stride_masks apart) receive GraphReplayBuffer.insert's mask rules for the
+ * step (see gmpe_masks_from_dones). Not available for handles on the split big-E path (gmpe_tuning.split): returns
+ * GMPE_ERR_UNSUPPORTED there — use gmpe_step_many. */
+typedef struct gmpe_rollout {
+    int32_t num_steps;          /* K >= 1                                                                  */
+    int32_t num_action_sets;    /* S: step k uses action set k % S of actions_dev (i32 [S,N,A])            */
+    int32_t num_slots;          /* >= 1                                                                    */
+    int32_t first_slot;         /* in [0, num_slots)                                                       */
+    int64_t stride_obs, stride_agent_id, stride_node_obs, stride_adj, stride_reward, stride_done, stride_info, stride_masks;
+    float*  masks;              /* slot 0 of the masks, or NULL                                            */
+    float*  active_masks;       /* slot 0 of the active_masks, or NULL                                     */
+} gmpe_rollout;
+int gmpe_rollout_steps(gmpe_handle* h, const int32_t* actions_dev, const gmpe_rollout* plan, const gmpe_outputs* slot0, void* stream);
 
 /* Optional: record the `num_steps` launches of gmpe_step_many(actions_dev, num_steps, num_action_sets, out) into a
  * hipGraph once (capture on a private stream + instantiate: milliseconds, not on the step path). Later
  * gmpe_step_many calls with the SAME pointers and counts replay it with one hipGraphLaunch on the caller's stream
  * (kernel-to-kernel dispatch overhead 3.6 -> 1.6 us at this launch shape, profiles/README.md); any other call takes
- * the plain launch loop. The action / output BUFFERS are baked in, their contents are read at replay time. */
+ * the plain launch loop. The action / output BUFFERS are baked in, their contents are read at replay time.
+ * Since round 2 gmpe_step_many runs the rollout kernel above by default (gmpe_tuning.roll); a prepared graph is what it falls back to
+ * when that is off (GMPE_ROLL=0) or unavailable (split path, per-launch timing). */
 int gmpe_step_many_prepare(gmpe_handle* h, const int32_t* actions_dev, int32_t num_steps, int32_t num_action_sets,
                            const gmpe_outputs* out);
 
@@ -230,6 +257,25 @@ int gmpe_edges_from_adj(gmpe_handle* h, const float* adj_dev, int32_t batch, int
  * rules graph_mpe_runner.py:85-90, 395-405): masks f32 [N,A] = 0 where done; active_masks f32 [N,A] = 0 where done unless all agents of
  * the env are done. Either output may be NULL. */
 int gmpe_masks_from_dones(gmpe_handle* h, const uint8_t* done_dev, float* masks_dev, float* active_masks_dev, void* stream);
+
+/* What gmpe_create chose for this handle (recorded by bench.py next to every number). The GMPE_G / GMPE_BLOCK / GMPE_NT /
+ * GMPE_SPEC / GMPE_SPLIT / GMPE_ROLL environment variables override the heuristics; none of them changes results
+ * (tests/test_gpu_instantiations.py). */
+typedef struct gmpe_tuning {
+    int32_t G;                  /* envs per workgroup (tile)                                               */
+    int32_t block;              /* threads per workgroup: 64, 128 or 256                                   */
+    int32_t nt;                 /* 1: nontemporal graph stores (launch output > Infinity Cache)            */
+    int32_t spec;               /* 1: wave-specialised tiles                                               */
+    int32_t split;              /* 1: big-E path — fused kernel writes the compact [N,E,E] matrix into the handle's scratch,
+                                      k_adj_expand materialises the A ego copies                           */
+    int32_t roll;               /* 1: gmpe_step_many runs the persistent rollout kernel                    */
+    int32_t ap;                 /* exact-size instantiation (0: run-time sizes)                            */
+    int32_t lds_bytes;          /* dynamic LDS per tile                                                    */
+    int32_t diag_build;         /* 1: library built with -DGMPE_DIAG (ablations honoured): never for results */
+    int32_t G_roll, block_roll; /* tile shape of the rollout kernel (its own register budget, hence its own residency)  */
+    int32_t reserved[5];
+} gmpe_tuning;
+int gmpe_get_tuning(const gmpe_handle* h, gmpe_tuning* out);
 
 /* Timing hooks used by bench.py: HIP events on the handle's launch stream around every step
  * kernel, so the dominant kernel's duration is measured live (not via torch's current stream). */

@@ -15,8 +15,8 @@ _lib = None
 
 
 def build(force=False):
-    src = os.path.join(ORACLE_DIR, "gmpe_oracle.c")
-    if force or not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(src):
+    srcs = [os.path.join(ORACLE_DIR, "gmpe_oracle.c"), os.path.join(ROOT, "include", "gmpe.h")]
+    if force or not os.path.exists(SO) or any(os.path.getmtime(SO) < os.path.getmtime(q) for q in srcs):
         subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
     return SO
 

@@ -20,27 +20,58 @@ def _bench(*flags):
 
 
 def test_default_line_has_every_contract_field():
-    d = _bench("--no-cpu-baseline")
+    d = _bench("--no-cpu-baseline", "--reps", "3")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline"):             # cpu_baseline: next test (skipped here for speed)
+              "vs_baseline", "dtype", "data", "config", "roofline", "repetitions", "closed_loop", "numpy_boundary"):   # cpu_baseline: next test
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 3 and d["higher_is_better"] is True
     assert d["unit"] == "env-steps/s" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
-    assert d["config"]["key"] == "c2" and d["config"]["envs_per_gpu"] == 4096 and "model" not in d["config"]
+    assert d["metric"] == "env-steps/sec (whole node) at 4096 envs x 10 agents, navigation_graph"
+    c = d["config"]
+    assert c["key"] == "c2" and c["envs_per_gpu"] == 4096 and "model" not in c and "parity unpinned" in c["workload"]
+    assert c["tuning"]["roll"] == 1 and c["tuning"]["diag_build"] == 0 and c["env"] == {} and c["diag"] is False
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["launches"] == 20
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["launches"] == 1 and r["env_steps_per_launch"] == 4096 * 20      # the K steps are ONE launch of the rollout kernel
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     # achieved = algorithmic bytes per launch / average launch duration (HIP events on the launch stream)
     assert abs(r["achieved"] - r["algorithmic_bytes_per_env_step"] * r["env_steps_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["algorithmic_bytes_per_env_step"] == 24010
     assert abs(d["value"] - 4096 * 20 / (d["ms_per_step"] * 1e-3 * 20)) < 1e-6 * d["value"]
+    rp = d["repetitions"]
+    assert rp["n"] == 3 and len(rp["env_steps_per_s"]) == 3 and sorted(rp["env_steps_per_s"])[1] == d["value"]   # the median is reported
+    assert d["closed_loop"]["launches"] == 20 and d["closed_loop"]["ms_per_step"] > 0
+    assert d["numpy_boundary"]["value"] > 1e5 and d["numpy_boundary"]["value"] < d["value"]
     assert d["value"] > 1e6                                  # BASELINE.json target on one MI355X
 
 
+def test_launch_loop_and_compact_lines_price_their_own_bytes():
+    d = _bench("--no-cpu-baseline", "--no-boundary", "--launch-loop", "--reps", "1")
+    assert d["roofline"]["launches"] == 20 and d["roofline"]["env_steps_per_launch"] == 4096 and "closed_loop" not in d
+    c = _bench("--no-cpu-baseline", "--no-boundary", "--adj-compact", "--reps", "1")
+    A, E, F, D = 10, 20, 8, 13
+    assert c["roofline"]["algorithmic_bytes_per_env_step"] == 4 * (E * E + A * (E * F + D + 2)) + A + 4 * A + 2 * A * 48
+
+
+def test_diagnostic_knobs_are_refused_and_perf_knobs_recorded():
+    env = dict(os.environ, GMPE_ABLATE="3")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "GMPE_ABLATE" in out.stderr
+    env = dict(os.environ, GMPE_G="6", GMPE_ROLL="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--reps", "1", "--no-cpu-baseline", "--no-boundary"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-1500:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["config"]["env"] == {"GMPE_G": "6", "GMPE_ROLL": "0"} and d["config"]["tuning"]["G"] == 6 and d["config"]["tuning"]["roll"] == 0
+    assert d["roofline"]["launches"] == 5                       # no rollout kernel -> one launch per step
+
+
 def test_cpu_baseline_leg_and_other_workload():
-    d = _bench("--workload", "c3r", "--envs", "512")
+    d = _bench("--workload", "c3r", "--envs", "512", "--reps", "2", "--no-boundary")
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "env-steps/s" and cb["value"] > 0 and "sample" in cb
-    assert d["config"]["obs_dim"] == 13 and d["config"]["envs_per_gpu"] == 512
+    assert d["config"]["obs_dim"] == 13 and d["config"]["envs_per_gpu"] == 512 and d["config"]["node_feats"] == 7
+    assert d["metric"].startswith("env-steps/sec (whole node), nav_graph_metered_single_corridor_rot_inv")
 
 
 def test_smoke_entry():

@@ -1,0 +1,213 @@
+"""The persistent rollout kernel (gmpe_rollout_steps, k_env<*, 0, SC, 2>): K steps in ONE launch must be bit-identical to K
+launches of the step kernel — outputs of every step (slot-per-step placement), masks, final state, RNG counters — for every
+scenario variant, with auto-resets inside the rollout, mixed tiles, single- and multi-wave tiles.
+
+What it replaces: the runner's collect loop with a fixed action source (onpolicy/runner/shared/graph_mpe_runner.py:57-103 →
+envs.step → GraphReplayBuffer.insert, onpolicy/utils/graph_buffer.py:168-251).
+"""
+import numpy as np
+import pytest
+
+import gmpe
+import oracle_lib as ol
+from test_gpu_parity import ROTFAM, TOL, _compare_state, _engine, _np
+
+pytestmark = pytest.mark.gpu
+JULY = "nav_metered_one_goal_graph_rotate_tube_july"
+OUT_KEYS = ("obs", "agent_id", "node_obs", "adj", "reward", "done", "info")
+
+
+def _slots(eng, T):
+    """Slot-per-step output storage [T, ...] for every output of the engine + masks."""
+    import torch
+    st = {k: torch.zeros((T,) + tuple(getattr(eng.out, k).shape), dtype=getattr(eng.out, k).dtype, device="cuda") for k in OUT_KEYS}
+    st["masks"] = torch.full((T, eng.N, eng.A), -1.0, device="cuda")
+    st["active"] = torch.full((T, eng.N, eng.A), -1.0, device="cuda")
+    return st
+
+
+def _rollout_into_slots(eng, acts, K, T, first=0):
+    from gmpe.engine import StepOutputs
+    st = _slots(eng, T)
+    slot0 = StepOutputs(**{k: st[k][0] for k in OUT_KEYS})
+    strides = {k: st[k][0].numel() for k in OUT_KEYS}
+    strides["masks"] = eng.N * eng.A
+    eng.rollout(acts, K, slot0=slot0, num_slots=T, first_slot=first, strides=strides, masks=st["masks"], active_masks=st["active"])
+    return st
+
+
+CASES = [
+    dict(scenario_name="navigation_graph", num_envs=40, num_agents=10, world_size=4.0, episode_length=7, seed=71),
+    dict(scenario_name="navigation_graph", num_envs=23, num_agents=6, num_obstacles=3, num_walls=4, world_size=3.0, episode_length=6, seed=72),
+    dict(scenario_name=JULY, num_envs=50, num_agents=10, world_size=4.0, episode_length=8, seed=73),
+    dict(scenario_name=ROTFAM[0], num_envs=31, num_agents=10, world_size=4.0, episode_length=8, seed=74),
+    dict(scenario_name=ROTFAM[1], num_envs=31, num_agents=4, world_size=2.4, episode_length=9, seed=75),
+    dict(scenario_name=ROTFAM[2], num_envs=18, num_agents=10, world_size=4.0, episode_length=8, seed=76),
+    dict(scenario_name="navigation_graph", num_envs=5, num_agents=32, num_obstacles=8, num_walls=4, world_size=8.0, episode_length=4, seed=77),
+    dict(scenario_name=JULY, num_envs=3, num_agents=64, world_size=30.0, episode_length=3, seed=78),
+]
+
+
+@pytest.mark.parametrize("shape", [None, (2, 64), (3, 256), (6, 256)], ids=["auto", "G2-B64", "G3-B256", "G6-B256"])
+@pytest.mark.parametrize("kw", CASES, ids=["%s-A%d-O%d" % (c["scenario_name"][:10], c["num_agents"], c.get("num_obstacles", 0)) for c in CASES])
+def test_rollout_kernel_equals_step_loop(monkeypatch, kw, shape):
+    import torch
+    if shape:
+        if shape[0] * kw["num_agents"] > 64:
+            pytest.skip("G*A > 64")
+        monkeypatch.setenv("GMPE_G", str(shape[0])); monkeypatch.setenv("GMPE_BLOCK", str(shape[1]))
+    monkeypatch.setenv("GMPE_SPLIT", "0")
+    cfg = gmpe.make_config(**kw)
+    e1, e2 = _engine(cfg), _engine(cfg)
+    e1.reset(); e2.reset()
+    N, A = cfg.num_envs, cfg.num_agents
+    K, S, T = 19, 5, 19
+    g = torch.Generator(device="cuda"); g.manual_seed(kw["seed"])
+    acts = torch.randint(0, cfg.n_actions, (S, N, A), generator=g, device="cuda", dtype=torch.int32)
+    ref = {k: [] for k in OUT_KEYS}
+    dones = []
+    for k in range(K):
+        o = e1.step(acts[k % S])
+        for key in OUT_KEYS:
+            ref[key].append(getattr(o, key).clone())
+        dones.append(o.done.clone())
+    st = _rollout_into_slots(e2, acts, K, T)
+    torch.cuda.synchronize()
+    n_all_done = 0
+    for k in range(K):
+        for key in OUT_KEYS:
+            assert torch.equal(st[key][k], ref[key][k]), (key, k)
+        d = dones[k].bool()
+        alld = d.all(dim=1, keepdim=True)
+        n_all_done += int(alld.sum())
+        assert torch.equal(st["masks"][k], (~d).float()), ("masks", k)
+        assert torch.equal(st["active"][k], (~(d & ~alld)).float()), ("active_masks", k)
+    assert n_all_done >= N                                   # auto-resets happened inside the rollout
+    _compare_state(e1, e2, "after rollout")
+    # a second rollout continues from the carried-back state; single slot this time (every step overwrites the same buffers)
+    for k in range(7):
+        o1 = e1.step(acts[k % S])
+    o2 = e2.rollout(acts, 7)
+    for key in OUT_KEYS:
+        assert torch.equal(getattr(o1, key), getattr(o2, key)), key
+    _compare_state(e1, e2, "after second rollout")
+    e1.check_errors(); e2.check_errors()
+
+
+def test_rollout_kernel_vs_oracle_every_step():
+    """The rollout kernel against the CPU oracle directly (not only against the step kernel)."""
+    import torch
+    cfg = gmpe.make_config(scenario_name=JULY, num_envs=64, num_agents=10, world_size=4.0, episode_length=9, seed=81)
+    eng, orc = _engine(cfg), ol.Oracle(cfg)
+    eng.reset(); orc.reset()
+    K = 24
+    rng = np.random.RandomState(5)
+    acts = rng.randint(0, 25, (K, 64, 10)).astype(np.int32)
+    st = _rollout_into_slots(eng, torch.as_tensor(acts, device="cuda"), K, K)
+    for k in range(K):
+        oo = orc.step(acts[k])
+        np.testing.assert_allclose(_np(st["obs"][k]), oo[0], rtol=0, atol=TOL, err_msg="obs %d" % k)
+        np.testing.assert_allclose(_np(st["node_obs"][k]), oo[2], rtol=0, atol=TOL, err_msg="node %d" % k)
+        np.testing.assert_allclose(_np(st["adj"][k]), np.broadcast_to(oo[3][:, None], st["adj"][k].shape), rtol=0, atol=TOL, err_msg="adj %d" % k)
+        np.testing.assert_allclose(_np(st["reward"][k]), oo[4], rtol=0, atol=TOL, err_msg="rew %d" % k)
+        np.testing.assert_array_equal(_np(st["done"][k]).astype(bool), oo[5], err_msg="done %d" % k)
+        np.testing.assert_allclose(_np(st["info"][k]), oo[6], rtol=2e-6, atol=2e-5, err_msg="info %d" % k)
+    _compare_state(eng, orc, "end")
+
+
+def test_rollout_slots_wrap_and_tape_mode():
+    """first_slot > 0 with wrap-around (slot = (first + k) % num_slots), and the RNG tape (parity mode) inside a rollout."""
+    import torch
+    cfg = gmpe.make_config(scenario_name=ROTFAM[0], num_envs=20, num_agents=5, world_size=4.0, episode_length=5, seed=91)
+    e1, e2 = _engine(cfg), _engine(cfg)
+    tape = np.random.RandomState(2).rand(20, 4096)
+    e1.set_tape(tape); e2.set_tape(tape)
+    e1.reset(); e2.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    acts = torch.randint(0, 25, (4, 20, 5), generator=g, device="cuda", dtype=torch.int32)
+    T, K, first = 6, 10, 4
+    ref = {}
+    for k in range(K):
+        o = e1.step(acts[k % 4])
+        ref[(first + k) % T] = {key: getattr(o, key).clone() for key in OUT_KEYS}      # later steps overwrite wrapped slots
+    st = _rollout_into_slots(e2, acts, K, T, first=first)
+    for s in range(T):
+        for key in OUT_KEYS:
+            assert torch.equal(st[key][s], ref[s][key]), (key, s)
+    _compare_state(e1, e2, "tape")
+    e1.check_errors(); e2.check_errors()
+
+
+def test_step_many_takes_the_rollout_kernel_and_falls_back(monkeypatch):
+    """gmpe_step_many = one launch of the rollout kernel by default; GMPE_ROLL=0 keeps the launch loop. Same results."""
+    import torch
+    cfg = gmpe.make_config(scenario_name="navigation_graph", num_envs=70, num_agents=10, seed=8, episode_length=9)
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    acts = torch.randint(0, 5, (7, 70, 10), generator=g, device="cuda", dtype=torch.int32)
+    e1 = _engine(cfg); assert e1.tuning()["roll"] == 1
+    monkeypatch.setenv("GMPE_ROLL", "0")
+    e2 = _engine(cfg); assert e2.tuning()["roll"] == 0
+    e1.reset(); e2.reset()
+    o1, o2 = e1.step_many(acts, 23), e2.step_many(acts, 23)
+    for k in OUT_KEYS:
+        assert torch.equal(getattr(o1, k), getattr(o2, k)), k
+    _compare_state(e1, e2, "roll vs loop")
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_device_rollout_buffer_collect_equals_insert_loop(compact):
+    """DeviceRolloutBuffer.collect (one launch for the whole T-step rollout) == T insert_step calls."""
+    import torch
+    from gmpe.engine import GmpeEngine
+    from gmpe.rollout import DeviceRolloutBuffer
+    N, A, T = 36, 10, 12
+    cfg = gmpe.make_config(num_envs=N, num_agents=A, episode_length=5, seed=19)
+    e1, e2 = GmpeEngine(cfg, adj_compact=compact), GmpeEngine(cfg, adj_compact=compact)
+    b1, b2 = DeviceRolloutBuffer(e1, T), DeviceRolloutBuffer(e2, T)
+    b1.warmup(); b2.warmup()
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    acts = torch.randint(0, 25, (T, N, A), generator=g, device="cuda", dtype=torch.int32)
+    for rep in range(2):
+        for t in range(T):
+            b1.insert_step(acts[t])
+        b2.collect(acts)
+        torch.cuda.synchronize()
+        for name in ("obs", "node_obs", "_adj", "agent_id", "rewards", "dones", "masks", "active_masks", "info"):
+            assert torch.equal(getattr(b1, name), getattr(b2, name)), (rep, name)
+        assert b1.step == b2.step == 0
+        assert torch.equal(e1.out.obs, e2.out.obs) and e1.out.obs.data_ptr() == b1.obs[T].data_ptr()
+        b1.after_update(); b2.after_update()
+    # partial collects: 5 + 7 steps
+    for t in range(T):
+        b1.insert_step(acts[t])
+    b2.collect(acts[:5], 5); assert b2.step == 5
+    b2.collect(acts[5:], 7); assert b2.step == 0
+    for name in ("obs", "node_obs", "_adj", "rewards", "masks", "active_masks"):
+        assert torch.equal(getattr(b1, name), getattr(b2, name)), name
+
+
+def test_full_size_rollout_c2_properties_and_slice():
+    """The launch bench.py times by default (c2: 4096 x 10 navigation_graph, K steps in one launch): a 512-env oracle slice of the
+    final step + the graph invariants."""
+    import torch
+    kw = dict(scenario_name="navigation_graph", num_agents=10, world_size=4.0, episode_length=25, seed=1234)
+    cfg = gmpe.make_config(num_envs=4096, **kw)
+    eng, orc = _engine(cfg), ol.Oracle(gmpe.make_config(num_envs=512, **kw))
+    eng.reset(); orc.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(42)
+    K = 60
+    acts = torch.randint(0, cfg.n_actions, (K, 4096, 10), generator=g, device="cuda", dtype=torch.int32)
+    o = eng.step_many(acts, K)
+    a = acts[:, :512].cpu().numpy()
+    for k in range(K):
+        oo = orc.step(a[k])
+    np.testing.assert_allclose(_np(o.obs[:512]), oo[0], rtol=0, atol=TOL)
+    np.testing.assert_allclose(_np(o.node_obs[:512]), oo[2], rtol=0, atol=TOL)
+    np.testing.assert_allclose(_np(o.adj[:512]), np.broadcast_to(oo[3][:, None], (512, 10, 20, 20)), rtol=0, atol=TOL)
+    np.testing.assert_allclose(_np(o.reward[:512]), oo[4], rtol=0, atol=TOL)
+    np.testing.assert_array_equal(_np(o.done[:512]).astype(bool), oo[5])
+    np.testing.assert_array_equal(eng.get("rng_ctr")[:512], orc.get("rng_ctr"))
+    np.testing.assert_array_equal(eng.get("current_step")[:512], orc.get("current_step"))
+    adj = o.adj
+    assert torch.equal(adj, adj.transpose(-1, -2)) and torch.equal(adj, adj[:, :1].expand_as(adj))
+    eng.check_errors()

@@ -143,3 +143,37 @@ def test_returned_arrays_stay_valid_for_one_more_step():
     for x, y in zip(o2[:6], p2[:6]):
         np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
     envs.close(); envs2.close()
+
+
+@pytest.mark.parametrize("scen,mode", [("nav_metered_one_goal_graph_rotate_tube_july", "gather"),
+                                       ("nav_graph_metered_single_corridor_rot_inv", "gather"),
+                                       ("three_phase_graph", "all_gather")])
+def test_rollout_gather_real_engine(scen, mode):
+    """RolloutGather over RCCL with the REAL engine (world_size 1 covers slab binding, the collective call and unpack): the
+    unpacked arrays are the engine's outputs bit for bit, for an F = 8 and F = 7 scenario. Replaces env_wrappers.py:996-1004."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from gmpe.engine import GmpeEngine
+    from gmpe.sharding import RolloutGather
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29400 + os.getpid() % 500), rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    N, A = 48, 10
+    cfg = gmpe.make_config(scenario_name=scen, num_envs=N, num_agents=A, world_size=4.0, episode_length=5, seed=33)
+    e_ref, e_g = GmpeEngine(cfg, adj_compact=True), GmpeEngine(cfg, adj_compact=True)
+    e_ref.reset(); e_g.reset()
+    rg = RolloutGather(e_g, 1, mode=mode)
+    assert rg.dims[4] == cfg.node_feats
+    g = torch.Generator(device="cuda"); g.manual_seed(9)
+    for t in range(11):
+        act = torch.randint(0, 25, (N, A), generator=g, device="cuda", dtype=torch.int32)
+        o = e_ref.step(act)
+        rg.step_and_gather(act)
+        u = rg.unpack()
+        for k in ("obs", "node_obs", "adj", "reward"):
+            assert torch.equal(u[k], getattr(o, k)), (t, k)
+        assert torch.equal(u["done"], o.done.bool()), t
+    with pytest.raises(ValueError):
+        RolloutGather(GmpeEngine(cfg), 1)                  # needs the compact adjacency

@@ -172,51 +172,93 @@ def test_shard_ranges_cover_all_envs():
         assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
 
 
-def _gather_worker(rank, world, port, q):
+class _OracleBackedEngine(object):
+    """Host stand-in with GmpeEngine's surface (cfg / out / rebind / step / adj_compact / device) whose `step` fills the BOUND
+    output tensors from the CPU oracle — so the gather path (slab views, rebind, collective, unpack) runs on CPU with the real
+    shapes and values of a real config. Test infrastructure only; the GPU twin is tests/test_gpu_vec_env.py::test_rollout_gather_real_engine."""
+
+    def __init__(self, cfg):
+        import torch
+        import oracle_lib as ol
+        from gmpe.engine import StepOutputs
+        self.cfg, self.adj_compact, self.device = cfg, True, torch.device("cpu")
+        N, A, E, D, F = cfg.num_envs, cfg.num_agents, cfg.num_entities, cfg.obs_dim, cfg.node_feats
+        self.orc = ol.Oracle(cfg)
+        self.orc.reset()
+        self.out = StepOutputs(obs=torch.zeros(N, A, D), agent_id=torch.zeros(N, A, 1, dtype=torch.int32), node_obs=torch.zeros(N, A, E, F),
+                               adj=torch.zeros(N, E, E), reward=torch.zeros(N, A), done=torch.zeros(N, A, dtype=torch.uint8), info=None)
+
+    def rebind(self, o):
+        for k in ("obs", "node_obs", "adj", "reward", "done"):
+            assert getattr(o, k).shape == getattr(self.out, k).shape and getattr(o, k).dtype == getattr(self.out, k).dtype and getattr(o, k).is_contiguous(), k
+        self.out = o
+
+    def step(self, act):
+        import torch
+        obs, ids, node, adj, rew, done, info, did = self.orc.step(act)
+        o = self.out
+        o.obs.copy_(torch.from_numpy(obs)); o.node_obs.copy_(torch.from_numpy(node)); o.adj.copy_(torch.from_numpy(adj))
+        o.reward.copy_(torch.from_numpy(rew)); o.done.copy_(torch.from_numpy(done.astype(np.uint8)))
+        return o
+
+
+def _gather_worker(rank, world, port, q, scen, mode):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from gmpe.sharding import RolloutGather
-    N, A, E, D = 4, 3, 6, 19
-
-    class FakeCfg: num_envs, num_agents, num_entities, obs_dim = N, A, E, D
-
-    class FakeOut: pass
-
-    class FakeEngine:
-        cfg = FakeCfg(); adj_compact = True; device = torch.device("cpu")
-
-        def step(self, act):
-            o = FakeOut()
-            base = 1000.0 * (rank + 1)
-            o.obs = base + torch.arange(N * A * D, dtype=torch.float32).reshape(N, A, D)
-            o.node_obs = base + 0.5 + torch.arange(N * A * E * 8, dtype=torch.float32).reshape(N, A, E, 8)
-            o.adj = base + 0.25 + torch.arange(N * E * E, dtype=torch.float32).reshape(N, E, E)
-            o.reward = torch.full((N, A), float(rank))
-            o.done = torch.tensor([[rank == 1] * A] * N, dtype=torch.uint8)
-            return o
-
-    rg = RolloutGather(FakeEngine(), world)
-    rg.step_and_gather(None)
-    u = rg.unpack()
-    ok = (u["obs"].shape == (world * N, A, D) and u["adj"].shape == (world * N, E, E)
-          and float(u["obs"][0, 0, 0]) == 1000.0 and float(u["obs"][N, 0, 0]) == 2000.0
-          and bool((u["reward"][N:] == 1).all()) and bool(u["done"][N:].all()) and not bool(u["done"][:N].any()))
-    q.put((rank, ok))
+    import oracle_lib as ol
+    from gmpe.sharding import RolloutGather, shard_range
+    NT, A = 12, 4
+    kw = dict(scenario_name=scen, num_agents=A, world_size=4.0, episode_length=4, seed=5)
+    lo, hi = shard_range(NT, world, rank)
+    eng = _OracleBackedEngine(gmpe.make_config(num_envs=hi - lo, env_id_base=lo, **kw))
+    full = ol.Oracle(gmpe.make_config(num_envs=NT, **kw))
+    full.reset()
+    rg = RolloutGather(eng, world, mode=mode)
+    rng = np.random.RandomState(1)
+    ok = True
+    for t in range(9):                                        # two auto-resets inside; slabs alternate
+        act = rng.randint(0, eng.cfg.n_actions, (NT, A)).astype(np.int32)
+        ref = full.step(act)
+        rg.step_and_gather(act[lo:hi])
+        u = rg.unpack()
+        if mode == "gather" and rank != 0:
+            ok = ok and u is None
+            continue
+        F = eng.cfg.node_feats
+        ok = ok and u["node_obs"].shape == (NT, A, eng.cfg.num_entities, F) and u["done"].dtype == torch.bool
+        for k, r in (("obs", ref[0]), ("node_obs", ref[2]), ("adj", ref[3]), ("reward", ref[4])):
+            ok = ok and np.array_equal(u[k].numpy(), r.astype(np.float32))
+        ok = ok and np.array_equal(u["done"].numpy(), ref[5])
+    q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
 
-def test_rollout_gather_world_size_2_gloo():
+@pytest.mark.parametrize("scen,mode", [("nav_metered_one_goal_graph_rotate_tube_july", "gather"), ("nav_graph_metered_single_corridor_rot_inv", "gather"),
+                                       ("two_phase_graph", "all_gather"), ("navigation_graph", "all_gather")])
+def test_rollout_gather_world_size_2_gloo(scen, mode):
+    """Sharded oracle-backed engines + the gather == the unsharded run, for F = 8 and F = 7 scenarios, both collective modes."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    ps = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + (hash((scen, mode)) % 50)
+    ps = [ctx.Process(target=_gather_worker, args=(r, 2, port, q, scen, mode)) for r in range(2)]
     [p.start() for p in ps]
-    res = sorted(q.get(timeout=120) for _ in range(2))
+    res = sorted(q.get(timeout=180) for _ in range(2))
     [p.join(60) for p in ps]
     assert res == [(0, True), (1, True)]
+
+
+def test_rollout_gather_rejects_unequal_shards_and_wrong_layout():
+    from gmpe.sharding import slab_layout, slab_views
+    import torch
+    lay, nbytes = slab_layout(5, 3, 6, 13, 7)
+    assert nbytes % 16 == 0 and all(lo % 16 == 0 for lo, _ in lay.values())
+    v = slab_views(torch.zeros(nbytes, dtype=torch.uint8), lay, 5, 3, 6, 13, 7)
+    assert v["node_obs"].shape == (5, 3, 6, 7) and v["done"].dtype == torch.uint8 and v["adj"].shape == (5, 6, 6)
+    with pytest.raises(TypeError):
+        slab_layout(5, 3, 6, 13)                              # F has no default any more (round-1 bug: F = 8 assumed)
 
 
 # ---------------------------------------------------------------- oracle self-consistency (CPU)

@@ -2,7 +2,7 @@
 device rollout buffer. Prints one JSON line per piece (not the headline metric; see bench.py for that)."""
 import json, os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gmpe
 from gmpe.engine import GmpeEngine
 from gmpe.rollout import DeviceRolloutBuffer

@@ -1,6 +1,6 @@
-// tools_fillbw.hip — diagnostic (not product): what a pure streaming-store / copy kernel achieves on this GPU, to put
+// tools/fillbw.hip — diagnostic (not product): what a pure streaming-store / copy kernel achieves on this GPU, to put
 // roofline.frac (priced against the 8 TB/s spec peak) next to the write bandwidth the part really delivers.
-// build: hipcc -O3 --offload-arch=gfx950 tools_fillbw.hip -o gpurun_out/fillbw    run: gpurun_out/fillbw
+// build: hipcc -O3 --offload-arch=gfx950 tools/fillbw.hip -o gpurun_out/fillbw    run: gpurun_out/fillbw
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -1,7 +1,7 @@
 """Diagnostic: env-steps/s of the drop-in NumPy boundary (H2D one-hot actions + D2H observations every step)."""
 import argparse, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gmpe
 from gmpe.vec_env import BatchedGraphMPEVecEnv
 a = argparse.Namespace(env_name="GraphMPE", scenario_name="nav_metered_one_goal_graph_rotate_tube_july", dynamics_type="air_taxi",

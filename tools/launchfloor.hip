@@ -1,4 +1,4 @@
-// tools_launchfloor.hip — diagnostic (not product): back-to-back launch period of an EMPTY kernel with k_env's launch shape
+// tools/launchfloor.hip — diagnostic (not product): back-to-back launch period of an EMPTY kernel with k_env's launch shape
 // (683 workgroups x 256 threads, 40 KiB dynamic LDS) for a 1.1 KB by-value kernarg vs an 8-byte one, plain launches vs a hipGraph.
 #include <hip/hip_runtime.h>
 #include <stdio.h>

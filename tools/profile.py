@@ -1,12 +1,12 @@
-"""Summarises gpurun_out/{prof,pmcW,pmcF}_<wl>/ (tools_profile.sh) into profiles/: the kernel-stats CSV rows of our kernels and
-the per-launch HBM traffic JSON that bench.py copies into roofline.traffic. usage: python tools_profile.py c2 [round-tag]"""
+"""Summarises gpurun_out/{prof,pmcW,pmcF}_<wl>/ (tools/profile.sh) into profiles/: the kernel-stats CSV rows of our kernels and
+the per-launch HBM traffic JSON that bench.py copies into roofline.traffic. usage: python tools/profile.py c2 [round-tag]"""
 import csv
 import glob
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 csv.field_size_limit(1 << 30)
 

@@ -3,7 +3,7 @@
 #   gpurun_out/prof_<wl>/  --kernel-trace --stats      (average k_env duration)
 #   gpurun_out/pmcW_<wl>/  --pmc WRITE_SIZE            (separate passes, MI355X_MICROARCH.md HBM section)
 #   gpurun_out/pmcF_<wl>/  --pmc FETCH_SIZE
-# usage (inside gpurun): bash tools_profile.sh c2 [steps]     then, back in the container: python tools_profile.py c2
+# usage (inside gpurun): bash tools/profile.sh c2 [steps]     then, back in the container: python tools/profile.py c2
 set -e
 WL=${1:-c2}; STEPS=${2:-300}
 ROOT=$(pwd)

@@ -1,7 +1,7 @@
 """Diagnostic: event-timed k_env duration vs number of envs (fixed cost vs per-env cost)."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gmpe
 from gmpe.engine import GmpeEngine
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"

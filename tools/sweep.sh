@@ -1,5 +1,5 @@
 #!/bin/bash
-# tile-shape sweep on the GPU box: bash tools_sweep.sh <workload> "<G:BLOCK pairs, or 'auto'>" [envs]
+# tile-shape sweep on the GPU box: bash tools/sweep.sh <workload> "<G:BLOCK pairs, or 'auto'>" [envs]
 for gb in $2; do
   if [ "$gb" = auto ]; then unset GMPE_G GMPE_BLOCK; g=auto; b=auto; else g=${gb%%:*}; b=${gb##*:}; export GMPE_G=$g GMPE_BLOCK=$b; fi
   timeout -k 10 100 python bench.py --workload $1 ${3:+--envs $3} --steps 300 --warmup 30 --no-cpu-baseline > gpurun_out/sweep.json 2>gpurun_out/sweep.err

@@ -1,4 +1,4 @@
-// tools_waveplace.hip — diagnostic (not product): on which SIMD does wave w of a 256-thread workgroup land when 4 such workgroups
+// tools/waveplace.hip — diagnostic (not product): on which SIMD does wave w of a 256-thread workgroup land when 4 such workgroups
 // share a CU (k_env's C2 launch shape)? If every workgroup's wave 0 sat on the same SIMD, the wave-0-only phases of k_env would
 // serialise there.
 #include <hip/hip_runtime.h>
