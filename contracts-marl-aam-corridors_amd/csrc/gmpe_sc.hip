@@ -12,8 +12,8 @@ namespace gmpe {
 
 template <int SC>
 void launch_env(int block, int ap, int fl, dim3 grid, size_t lds, hipStream_t st, const KParams& p) {
-    if (fl == 2) {                                                       // persistent rollout kernel: BLOCK 64 or 256, run-time sizes (the exact-size
-        if (block == 64) hipLaunchKernelGGL((k_env<64, 0, SC, 2>), grid, dim3(64), lds, st, p);      // variants need > 168 VGPRs with the loop-carried state)
+    if (fl == 2) {                                                       // persistent rollout kernel: BLOCK 64 or 256, run-time sizes (<= 128 VGPRs = four
+        if (block == 64) hipLaunchKernelGGL((k_env<64, 0, SC, 2>), grid, dim3(64), lds, st, p);      // tiles per CU; the exact-size variants would spill there)
         else hipLaunchKernelGGL((k_env<256, 0, SC, 2>), grid, dim3(256), lds, st, p);
         return;
     }
