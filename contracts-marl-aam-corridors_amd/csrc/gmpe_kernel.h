@@ -31,6 +31,7 @@ struct KParams {
     const float* onehot;      // [N,A,n_actions] or nullptr
     const uint8_t* mask;      // reset mask or nullptr
     int mode;
+    int env_lo, env_hi;       // env range of this launch [lo, hi): the whole batch, or one chunk of the split big-E pipeline
     int A, L, O, E, D, F;     // F = node features per row (8, rot_inv: 7)
     int G;                    // envs per workgroup (G*A <= 64)
     int spec;                 // 1: multi-wave tiles specialise (wave 0 reward/info, waves 1.. graph stores)
@@ -154,14 +155,7 @@ __device__ __forceinline__ bool wall_band_hit(const KParams& p, double px, doubl
     }
     return false;
 }
-// Scenario.is_obstacle_collision (…_july.py:864-890) at an arbitrary point (reset placement)
-__device__ __forceinline__ bool obstacle_collision(const KParams& p, const Lds& l, double px, double py, double size) {
-    const int o0 = p.A + p.L;
-    for (int o = 0; o < p.O; ++o)
-        if (norm2(l.ex[o0 + o] - px, l.ey[o0 + o] - py) < 2.0 * (p.c.entity_size + size)) return true;
-    return wall_band_hit(p, px, py, size);
-}
-// same test for agent i at its current position, distances taken from the shared fp64 rows
+// Scenario.is_obstacle_collision (…_july.py:864-890) for agent i at its current position, distances taken from the shared fp64 rows
 __device__ __forceinline__ bool obstacle_collision_ego(const KParams& p, const Lds& l, int i) {
     const double* row = l.Dm + (size_t)i * p.E + p.A + p.L;
     for (int o = 0; o < p.O; ++o)
@@ -271,91 +265,132 @@ __device__ __forceinline__ void write_obs_rot(const KParams& p, const Lds& l, in
     } else o[12] = (float)phase;
 }
 
-// Serial reset of one env by ONE lane (reset_world: …_july.py:339-420, 440-515, 518-613,
-// custom_scenarios/utils.py:165-193; navigation_graph: DESIGN.md). Writes positions / headings to
-// LDS (ex, ey, n2, n3, tube) and landmark / obstacle / tube records to HBM. Bounded rejection loop.
+// Reset of the envs of a tile by wave 0 (reset_world: …_july.py:339-420, 440-515, 518-613, custom_scenarios/utils.py:165-193;
+// navigation_graph: DESIGN.md). The reference places entities one after another with rejection sampling — inherently sequential
+// in the entity index, but each attempt's collision test against the already placed entities is not: every agent lane of the env
+// computes the SAME candidate (same draws of the env's stream, same arithmetic: no shuffles) and tests it against the entities it
+// OWNS (agent i; obstacles / landmarks i, i+A, ...: a lane only ever re-reads its own LDS writes), and one ballot over the env's
+// lanes decides. Draw order and count are exactly the sequential ones (oracle/gmpe_oracle.c restates the loop literally), the
+// rejection loop is bounded. One lane per env doing all of it serially cost 70 us per reset step at c2 and 4-5 ms at c4
+// (profiles/README.md): a chain of ~300-cycle fp64 sqrt per placed entity and attempt on a single lane.
+// All lanes of wave 0 call this (wave-uniform); `mine` = lane belongs to an env that resets. Writes positions / headings to LDS
+// (ex, ey, n2, n3, tube) and landmark / obstacle / tube records to HBM.
 template <int SC>
-__device__ __forceinline__ void reset_world_serial(const KParams& p, const Lds& l, int n, int64_t& ctr, int& err) {
+__device__ __forceinline__ void reset_world_coop(const KParams& p, const Lds& l, int n, int i, bool mine, unsigned long long emask, int64_t& ctr, int& err) {
     const gmpe_config& c = p.c;
     const double ws = c.world_size, size = c.entity_size;
     const int A = p.A, L = p.L, O = p.O;
+    const int o0 = A + L;
     if (sc_kinematic(SC)) {
-        (void)draw_at(c, p.s, n, ctr++, err);                              // wall_length draw, unused (:368)
-        const double a = 3 * size * 2.5, b = ws * 0.15;
-        const double width = a > b ? a : b;
-        const double angle = -M_PI / 2 + (M_PI / 2 - (-M_PI / 2)) * draw_at(c, p.s, n, ctr++, err);
-        double tl = ws * 0.8;
-        if (sc_phasefam(SC)) tl += -ws * 0.3 + (ws * 0.1 - (-ws * 0.3)) * draw_at(c, p.s, n, ctr++, err);   // two_phase_graph.py:506
-        const double ca = cos(angle), sa = sin(angle);
-        const double be = tl / 4, bx = -tl / 4;
-        const double entx = ca * 0 + sa * be, enty = -sa * 0 + ca * be;
-        const double exx = ca * 0 + sa * bx, exy = -sa * 0 + ca * bx;
-        const double dx = exx - entx, dy = exy - enty;
-        const double Lt = sqrt(dx * dx + dy * dy) + 1e-9;
-        const double ex = dx / Lt, ey = dy / Lt;
-        double* t = l.tube;
-        t[T_ANGLE] = angle; t[T_ENTX] = entx; t[T_ENTY] = enty; t[T_EXX] = exx; t[T_EXY] = exy;
-        t[T_EX] = ex; t[T_EY] = ey; t[T_NX] = (double)(float)(-ey); t[T_NY] = (double)(float)ex;
-        t[T_L] = Lt; t[T_HALFW] = width * 0.5; t[T_WIDTH] = width;
-        for (int q = 0; q < GMPE_TUBE_STRIDE; ++q) p.s.tube[(size_t)n * GMPE_TUBE_STRIDE + q] = t[q];
-        int k = 0, tries = 0;
-        while (k < A) {
-            const double u0 = draw_at(c, p.s, n, ctr++, err), u1 = draw_at(c, p.s, n, ctr++, err);
-            constexpr bool rot = sc_rotfam(SC);             // rot_inv.py:463, 469
-            const double jf = rot ? 0.3 : 0.2;
-            const double jx = jf * (-ws + (ws - (-ws)) * u0), jy = jf * (-ws + (ws - (-ws)) * u1);
-            const double dfe = rot ? (ws + k) / 3 : (ws + k) / 5;
-            const double px = entx + dfe * sa + jx, py = enty + dfe * ca + jy;
-            bool bad = obstacle_collision(p, l, px, py, size);
-            for (int q = 0; q < k && !bad; ++q) bad = norm2(l.ex[q] - px, l.ey[q] - py) < c.sep_dist;
-            if (bad && ++tries < GMPE_MAX_TRIES) continue;
-            if (bad) err |= 2;
-            l.ex[k] = px; l.ey[k] = py;
-            l.n2[k] = 0.0 + (2 * M_PI - 0.0) * draw_at(c, p.s, n, ctr++, err);
-            l.n3[k] = c.v_min;
-            ++k; tries = 0;
+        double entx = 0, enty = 0, exx = 0, exy = 0, sa = 0, ca = 1;
+        if (mine) {
+            (void)draw_at(c, p.s, n, ctr++, err);                              // wall_length draw, unused (:368)
+            const double a = 3 * size * 2.5, b = ws * 0.15;
+            const double width = a > b ? a : b;
+            const double angle = -M_PI / 2 + (M_PI / 2 - (-M_PI / 2)) * draw_at(c, p.s, n, ctr++, err);
+            double tl = ws * 0.8;
+            if (sc_phasefam(SC)) tl += -ws * 0.3 + (ws * 0.1 - (-ws * 0.3)) * draw_at(c, p.s, n, ctr++, err);   // two_phase_graph.py:506
+            ca = cos(angle); sa = sin(angle);
+            const double be = tl / 4, bx = -tl / 4;
+            entx = ca * 0 + sa * be; enty = -sa * 0 + ca * be;
+            exx = ca * 0 + sa * bx; exy = -sa * 0 + ca * bx;
+            const double dx = exx - entx, dy = exy - enty;
+            const double Lt = sqrt(dx * dx + dy * dy) + 1e-9;
+            const double ex = dx / Lt, ey = dy / Lt;
+            if (i == 0) {
+                double* t = l.tube;
+                t[T_ANGLE] = angle; t[T_ENTX] = entx; t[T_ENTY] = enty; t[T_EXX] = exx; t[T_EXY] = exy;
+                t[T_EX] = ex; t[T_EY] = ey; t[T_NX] = (double)(float)(-ey); t[T_NY] = (double)(float)ex;
+                t[T_L] = Lt; t[T_HALFW] = width * 0.5; t[T_WIDTH] = width;
+                for (int q = 0; q < GMPE_TUBE_STRIDE; ++q) p.s.tube[(size_t)n * GMPE_TUBE_STRIDE + q] = t[q];
+            }
         }
-        const double rel = -ws / 3;
-        const double rx = ca * 0.0 + sa * rel, ry = -sa * 0.0 + ca * rel;
-        for (int q = 0; q < L; ++q) { l.ex[A + q] = exx + rx; l.ey[A + q] = exy + ry; }
+        int k = 0, tries = 0;
+        double mx = 0, my = 0;                                              // agent i's accepted position (this lane owns agent i)
+        while (__ballot(mine && k < A)) {
+            if (mine && k < A) {
+                const double u0 = draw_at(c, p.s, n, ctr, err), u1 = draw_at(c, p.s, n, ctr + 1, err);
+                ctr += 2;
+                constexpr bool rot = sc_rotfam(SC);             // rot_inv.py:463, 469
+                const double jf = rot ? 0.3 : 0.2;
+                const double jx = jf * (-ws + (ws - (-ws)) * u0), jy = jf * (-ws + (ws - (-ws)) * u1);
+                const double dfe = rot ? (ws + k) / 3 : (ws + k) / 5;
+                const double px = entx + dfe * sa + jx, py = enty + dfe * ca + jy;
+                bool bad_i = wall_band_hit(p, px, py, size);
+                for (int o = i; o < O; o += A) bad_i = bad_i || norm2(l.ex[o0 + o] - px, l.ey[o0 + o] - py) < 2.0 * (size + size);
+                bad_i = bad_i || (i < k && norm2(mx - px, my - py) < c.sep_dist);
+                const bool bad = (__ballot(bad_i) & emask) != 0ull;
+                if (bad && ++tries < GMPE_MAX_TRIES) continue;
+                if (bad) err |= 2;
+                const double th = 0.0 + (2 * M_PI - 0.0) * draw_at(c, p.s, n, ctr++, err);
+                if (i == k) { mx = px; my = py; l.ex[k] = px; l.ey[k] = py; l.n2[k] = th; l.n3[k] = c.v_min; }
+                ++k; tries = 0;
+            }
+        }
+        if (mine) {
+            const double rel = -ws / 3;
+            const double rx = ca * 0.0 + sa * rel, ry = -sa * 0.0 + ca * rel;
+            for (int q = i; q < L; q += A) { l.ex[A + q] = exx + rx; l.ey[A + q] = exy + ry; }
+        }
     } else {
         const double lo = -ws / 2, hi = ws / 2;
-        for (int o = 0, tries = 0; o < O;) {
-            const double px = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr, err));
-            const double py = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr + 1, err));
-            ctr += 2;
-            bool bad = false;
-            for (int q = 0; q < o && !bad; ++q) bad = norm2(l.ex[A + L + q] - px, l.ey[A + L + q] - py) < 2.0 * (size + size);
-            if (bad && ++tries < GMPE_MAX_TRIES) continue;
-            if (bad) err |= 2;
-            l.ex[A + L + o] = px; l.ey[A + L + o] = py; ++o; tries = 0;
+        int k = 0, tries = 0;
+        // obstacles: >= 2*(size+size) apart; lane i owns obstacles i, i+A, ...
+        while (__ballot(mine && k < O)) {
+            if (mine && k < O) {
+                const double px = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr, err));
+                const double py = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr + 1, err));
+                ctr += 2;
+                bool bad_i = false;
+                for (int q = i; q < k; q += A) bad_i = bad_i || norm2(l.ex[o0 + q] - px, l.ey[o0 + q] - py) < 2.0 * (size + size);
+                const bool bad = (__ballot(bad_i) & emask) != 0ull;
+                if (bad && ++tries < GMPE_MAX_TRIES) continue;
+                if (bad) err |= 2;
+                if (k % A == i) { l.ex[o0 + k] = px; l.ey[o0 + k] = py; }
+                ++k; tries = 0;
+            }
         }
-        for (int k = 0, tries = 0; k < A;) {
-            const double px = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr, err));
-            const double py = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr + 1, err));
-            ctr += 2;
-            bool bad = obstacle_collision(p, l, px, py, size);
-            for (int q = 0; q < k && !bad; ++q) bad = norm2(l.ex[q] - px, l.ey[q] - py) < c.sep_dist;
-            if (bad && ++tries < GMPE_MAX_TRIES) continue;
-            if (bad) err |= 2;
-            l.ex[k] = px; l.ey[k] = py; l.n2[k] = 0.0; l.n3[k] = 0.0; ++k; tries = 0;
+        // agents: clear of obstacles / wall bands, >= sep_dist apart
+        k = 0; tries = 0;
+        double mx = 0, my = 0;
+        while (__ballot(mine && k < A)) {
+            if (mine && k < A) {
+                const double px = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr, err));
+                const double py = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr + 1, err));
+                ctr += 2;
+                bool bad_i = wall_band_hit(p, px, py, size);
+                for (int o = i; o < O; o += A) bad_i = bad_i || norm2(l.ex[o0 + o] - px, l.ey[o0 + o] - py) < 2.0 * (size + size);
+                bad_i = bad_i || (i < k && norm2(mx - px, my - py) < c.sep_dist);
+                const bool bad = (__ballot(bad_i) & emask) != 0ull;
+                if (bad && ++tries < GMPE_MAX_TRIES) continue;
+                if (bad) err |= 2;
+                if (i == k) { mx = px; my = py; l.ex[k] = px; l.ey[k] = py; l.n2[k] = 0.0; l.n3[k] = 0.0; }
+                ++k; tries = 0;
+            }
         }
-        for (int q = 0, tries = 0; q < L;) {
-            const double px = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr, err));
-            const double py = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr + 1, err));
-            ctr += 2;
-            bool bad = obstacle_collision(p, l, px, py, size);
-            for (int r = 0; r < q && !bad; ++r) bad = norm2(l.ex[A + r] - px, l.ey[A + r] - py) < c.sep_dist;
-            if (bad && ++tries < GMPE_MAX_TRIES) continue;
-            if (bad) err |= 2;
-            l.ex[A + q] = px; l.ey[A + q] = py; ++q; tries = 0;
+        // goals (landmarks): clear of obstacles / wall bands, >= sep_dist apart; lane i owns landmarks i, i+A, ...
+        k = 0; tries = 0;
+        while (__ballot(mine && k < L)) {
+            if (mine && k < L) {
+                const double px = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr, err));
+                const double py = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr + 1, err));
+                ctr += 2;
+                bool bad_i = wall_band_hit(p, px, py, size);
+                for (int o = i; o < O; o += A) bad_i = bad_i || norm2(l.ex[o0 + o] - px, l.ey[o0 + o] - py) < 2.0 * (size + size);
+                for (int r = i; r < k; r += A) bad_i = bad_i || norm2(l.ex[A + r] - px, l.ey[A + r] - py) < c.sep_dist;
+                const bool bad = (__ballot(bad_i) & emask) != 0ull;
+                if (bad && ++tries < GMPE_MAX_TRIES) continue;
+                if (bad) err |= 2;
+                if (k % A == i) { l.ex[A + k] = px; l.ey[A + k] = py; }
+                ++k; tries = 0;
+            }
         }
-        for (int o = 0; o < O; ++o) {
-            p.s.obstacles[((size_t)n * O + o) * 2] = l.ex[A + L + o];
-            p.s.obstacles[((size_t)n * O + o) * 2 + 1] = l.ey[A + L + o];
+        if (mine) for (int o = i; o < O; o += A) {
+            p.s.obstacles[((size_t)n * O + o) * 2] = l.ex[o0 + o];
+            p.s.obstacles[((size_t)n * O + o) * 2 + 1] = l.ey[o0 + o];
         }
     }
-    for (int q = 0; q < L; ++q) {
+    if (mine) for (int q = i; q < L; q += A) {
         p.s.landmarks[((size_t)n * L + q) * 2] = l.ex[A + q];
         p.s.landmarks[((size_t)n * L + q) * 2 + 1] = l.ey[A + q];
     }
@@ -466,7 +501,21 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
             } else for (int q = t0; q < Gv * EE; q += nthr) { const int gg = fdiv(q, EE, p.m_EE); if (l.flags[gg * 4 + 3]) dst[q] = l.M[(size_t)gg * EE4 + (q - gg * EE)]; }
         } else {
             float* dst = o.adj + (size_t)n0 * A * EE;
-            if (vec) {
+            if (vec && nt) {
+                // big launches (nontemporal stores): OUTPUT order — the tile writes each env's [A,E,E] block front to back, so the
+                // workgroups in flight stream whole 0.6-4 MB blocks like a fill (tools/expandbw.hip: 6.9 vs 5.7 TB/s for the
+                // lane-keeps-a-float4 order below, whose A copies open A write fronts per tile)
+                const int nq = EE / 4, per = A * nq;
+                for (int gg = 0; gg < Gv; ++gg) {
+                    if (!l.flags[gg * 4 + 3]) continue;
+                    const float4* M4 = reinterpret_cast<const float4*>(l.M + (size_t)gg * EE4);
+                    float4* d4 = reinterpret_cast<float4*>(dst) + (size_t)gg * per;
+                    for (int q = t0; q < per; q += nthr) {
+                        const int a = fdiv(q, nq, p.m_nq), m = q - a * nq;      // exact: q * nq < A * nq^2 < 2^32 (checked by gmpe_create)
+                        nt_store4(&d4[q], M4[m]);
+                    }
+                }
+            } else if (vec) {
                 const int nq = EE / 4;
                 // each lane keeps one float4 of the env's matrix and stores it to the A ego copies
                 for (int q = t0; q < Gv * nq; q += nthr) {
@@ -603,8 +652,8 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
     const int A = CT ? AP : p.A, L = CT ? AP : p.L, O = CT ? 0 : p.O, E = CT ? 2 * AP : p.E, D = CT ? (SC == SC_JULY ? 19 : (sc_phasefam(SC) ? 15 : 13)) : p.D, G = p.G, N = p.c.num_envs;
     const gmpe_config& c = p.c;
     const Lds l = carve(smem, G, A, E, D, SC == SC_NAV_WALLS ? p.c.num_walls : 0);
-    const int n0 = blockIdx.x * G;
-    const int Gv = min(G, N - n0);                                      // envs actually present in this tile
+    const int n0 = p.env_lo + blockIdx.x * G;
+    const int Gv = min(G, p.env_hi - n0);                               // envs actually present in this tile
     constexpr bool july = SC == SC_JULY, rotinv = SC == SC_ROT, rotfam = sc_rotfam(SC), two = SC == SC_TWO, three = SC == SC_THREE;
     constexpr int PV = two ? 1 : (three ? 2 : 0);                        // phase FSM variant (gmpe_device.h)
     const bool step = FL ? true : p.mode == MODE_STEP;
@@ -675,7 +724,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
     }
     if (tid < G) {
         const int nn = n0 + tid;
-        const bool active = nn < N && (step || !p.mask || p.mask[nn]);
+        const bool active = nn < p.env_hi && (step || !p.mask || p.mask[nn]);
         l.flags[tid * 4 + 0] = (!step && active); l.flags[tid * 4 + 1] = 0; l.flags[tid * 4 + 2] = 0; l.flags[tid * 4 + 3] = active;
     }
     if (t_ok) l.tube[tid] = tube0;
@@ -1207,14 +1256,16 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
             // ---- 5. reset (explicit, or the worker's auto-reset when every agent of the env is done)
             if (any_reset) {
                 const bool mine = ag && v.flags[0];
-                if (mine && i == 0) {                                             // one lane per resetting env
-                    int64_t ctr = ctr0 + (step ? v.flags[1] : 0);                // this step's heading re-draws come first
-                    reset_world_serial<SC>(p, v, n, ctr, err);
-                    if (ROLL) reinterpret_cast<long long*>(l.cntd + (size_t)G * A * 2 + G)[g] = ctr;
-                    p.s.rng_ctr[n] = ctr;
-                    p.s.current_step[n] = 0;
-                    p.s.delta_spacing[n] = 0.0;
-                    v.flags[2] = 0;
+                if (tid < 64) {                                                   // wave 0 holds every agent lane: placement is a wave-cooperative loop
+                    int64_t ctr = ctr0 + ((mine && step) ? v.flags[1] : 0);      // this step's heading re-draws come first
+                    reset_world_coop<SC>(p, v, n, i, mine, emask, ctr, err);
+                    if (mine && i == 0) {
+                        if (ROLL) reinterpret_cast<long long*>(l.cntd + (size_t)G * A * 2 + G)[g] = ctr;
+                        p.s.rng_ctr[n] = ctr;
+                        p.s.current_step[n] = 0;
+                        p.s.delta_spacing[n] = 0.0;
+                        v.flags[2] = 0;
+                    }
                 }
                 __syncthreads();
                 if (mine) {
@@ -1287,7 +1338,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
             }
             for (int q = tid; q < G * E; q += BLOCK) l.moff[q] = 0;
             if (tid < G) {
-                const bool active = n0 + tid < N;
+                const bool active = n0 + tid < p.env_hi;
                 l.flags[tid * 4 + 0] = 0; l.flags[tid * 4 + 1] = 0; l.flags[tid * 4 + 2] = 0; l.flags[tid * 4 + 3] = active;
             }
             slot = slot + 1 == p.num_slots ? 0 : slot + 1;

@@ -101,30 +101,26 @@ __global__ __launch_bounds__(256) void k_masks(const uint8_t* __restrict__ done,
 // ONE matrix (…_july.py:1625, 1647-1648), so the expansion is an exact broadcast. A pure streaming kernel at full
 // occupancy (no LDS, ~16 VGPRs): each lane loads one float4 of the matrix (read 1/A of the bytes written) and stores it to the A
 // copies with the nontemporal hint; a wave's store covers 1 KB contiguous, consecutive workgroups consecutive 4 KB of the same copy.
+// Store pattern (tools/expandbw.hip, profiles/r02_expandbw.log): OUTPUT-contiguous — blockIdx.x covers the A*nq float4 of one env's
+// [A,E,E] block, blockIdx.y strides over the envs of the chunk — so the workgroups in flight write whole 0.6-4 MB blocks front to
+// back like a fill (c4 784 us = 6.9 TB/s, c5 shard 1319 us = 6.5 TB/s; one lane per source float4 with A strided stores, the
+// pattern the fused kernel uses, reaches 5.7 / 5.4). The source float4 is re-read per copy: L2 hits.
 typedef float v4f_t2 __attribute__((ext_vector_type(4)));
-template <int U>
-__global__ __launch_bounds__(256) void k_adj_expand(const float* __restrict__ src, float* __restrict__ dst, uint32_t total4, uint32_t nq, int A) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;                 // total4 < 2^32 is checked by gmpe_create
-    if (t >= total4) return;
-    const long long n = t / nq;                                          // one 32-bit division per lane, amortised over the A stores
-    const int m = (int)(t - (uint32_t)n * nq);
-    const v4f_t2 val = reinterpret_cast<const v4f_t2*>(src)[t];
-    v4f_t2* d = reinterpret_cast<v4f_t2*>(dst) + n * (long long)A * nq + m;
-    int a = 0;
-    for (; a + U <= A; a += U) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(val, d + (long long)(a + u) * nq);
-    }
-    for (; a < A; ++a) __builtin_nontemporal_store(val, d + (long long)a * nq);
+__global__ __launch_bounds__(256) void k_adj_expand(const float* __restrict__ src, float* __restrict__ dst, int n_lo, int n_hi, uint32_t nq, int A, uint32_t m_nq) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x, per = (uint32_t)A * nq;
+    if (j >= per) return;
+    const uint32_t a = nq <= 1 ? j : __umulhi(j, m_nq), m = j - a * nq;              // exact: j * nq < 2^32 (checked by gmpe_create)
+    const v4f_t2* s4 = reinterpret_cast<const v4f_t2*>(src);
+    v4f_t2* d4 = reinterpret_cast<v4f_t2*>(dst);
+    for (int n = n_lo + blockIdx.y; n < n_hi; n += gridDim.y)
+        __builtin_nontemporal_store(s4[(size_t)n * nq + m], d4 + (size_t)n * per + j);
 }
 // scalar variant for E*E % 4 != 0 (odd E)
-__global__ __launch_bounds__(256) void k_adj_expand1(const float* __restrict__ src, float* __restrict__ dst, uint32_t total, uint32_t EE, int A) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= total) return;
-    const long long n = t / EE; const int m = (int)(t - (uint32_t)n * EE);
-    const float val = src[t];
-    float* d = dst + n * (long long)A * EE + m;
-    for (int a = 0; a < A; ++a) d[(long long)a * EE] = val;
+__global__ __launch_bounds__(256) void k_adj_expand1(const float* __restrict__ src, float* __restrict__ dst, int n_lo, int n_hi, uint32_t EE, int A) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x, per = (uint32_t)A * EE;
+    if (j >= per) return;
+    const uint32_t m = j % EE;
+    for (int n = n_lo + blockIdx.y; n < n_hi; n += gridDim.y) dst[(size_t)n * per + j] = src[(size_t)n * EE + m];
 }
 
 }  // namespace gmpe
@@ -152,6 +148,12 @@ struct gmpe_handle {
     int roll = 1;                    // gmpe_step_many runs the persistent rollout kernel
     int G_roll = 1, block_roll = 256;   // tile shape of the rollout kernel (its own register budget -> its own residency)
     float* adj_scratch = nullptr;    // [N,E,E] (split path only)
+    // split path: chunks of envs flow through two kernels on side streams — k_env(chunk c) on env_st[c & 1], k_adj_expand(chunk c)
+    // on exp_st after it — so the HBM-bound expansion of one chunk overlaps the latency-bound fused kernel of the next
+    int chunks = 1;
+    hipStream_t env_st[2] = {nullptr, nullptr}, exp_st = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ev_chunk;
     unsigned long long* stamps = nullptr;
     hipEvent_t region_ev[2] = {nullptr, nullptr};
     int32_t* edge_ws = nullptr;      // [cap_graphs] counts | [cap_graphs] offsets | [cap_graphs/1024+2] chunk sums
@@ -343,6 +345,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     {   // exact magic division (fdiv) needs q*d < 2^32 for every (range, divisor) pair the kernel uses
         const uint64_t S = (uint64_t)h->L + h->O;
         uint64_t d = (uint64_t)h->A * E;
+        if ((uint64_t)h->A * (E * E / 4) * (E * E / 4) >= (1ull << 32)) { gmpe_destroy(h); return fail(GMPE_ERR_UNSUPPORTED, "adjacency block too large for the index arithmetic"); }
         const uint64_t cand[] = {(uint64_t)E * E, S * S, (uint64_t)h->A * (h->A + h->O), (uint64_t)h->A * h->D, 2ull * E};
         for (uint64_t x : cand) if (x > d) d = x;
         if ((uint64_t)Gmax * d * d >= (1ull << 32)) { gmpe_destroy(h); return fail(GMPE_ERR_UNSUPPORTED, "tile too large for the index arithmetic"); }
@@ -378,15 +381,27 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
         const double out_bytes = (double)N * h->A * ((double)E * E + 8.0 * E) * 4.0;
         h->nt = getenv("GMPE_NT") ? atoi(getenv("GMPE_NT")) : (out_bytes > 192.0 * 1024 * 1024 ? 1 : 0);
         // The same launches split the adjacency fill from the fused kernel (see k_adj_expand): c4 1290 -> ~1030 us.
-        h->split = getenv("GMPE_SPLIT") ? atoi(getenv("GMPE_SPLIT")) : (out_bytes > 192.0 * 1024 * 1024 && h->A >= 8 ? 1 : 0);
+        h->split = getenv("GMPE_SPLIT") ? atoi(getenv("GMPE_SPLIT")) : (out_bytes > 192.0 * 1024 * 1024 && h->A >= 48 ? 1 : 0);
         if ((uint64_t)N * E * E >= (1ull << 32)) h->split = 0;            // k_adj_expand indexes the compact matrix with 32 bits
         h->roll = getenv("GMPE_ROLL") ? atoi(getenv("GMPE_ROLL")) : 1;
+        if ((uint64_t)h->A * E * E / 4 * (E * E / 4 + 1) >= (1ull << 32)) h->split = 0;   // k_adj_expand's exact magic division
         if (h->split) {
             void* q = nullptr;
             hipError_t e = hipMalloc(&q, (size_t)N * E * E * sizeof(float));
             if (e != hipSuccess) { gmpe_destroy(h); return fail(GMPE_ERR_HIP, std::string("hipMalloc(adjacency scratch): ") + hipGetErrorString(e)); }
             h->allocs.push_back(q);
             h->adj_scratch = static_cast<float*>(q);
+            h->chunks = getenv("GMPE_CHUNKS") ? atoi(getenv("GMPE_CHUNKS")) : 8;
+            if (h->chunks < 1) h->chunks = 1;
+            if ((size_t)h->chunks > N) h->chunks = (int)N;
+            bool ok = true;
+            for (int q2 = 0; q2 < 2 && ok; ++q2) ok = hipStreamCreateWithFlags(&h->env_st[q2], hipStreamNonBlocking) == hipSuccess;
+            ok = ok && hipStreamCreateWithFlags(&h->exp_st, hipStreamNonBlocking) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+            for (int q2 = 0; q2 < 3 && ok; ++q2) ok = hipEventCreateWithFlags(&h->ev_join[q2], hipEventDisableTiming) == hipSuccess;
+            h->ev_chunk.resize((size_t)h->chunks, nullptr);
+            for (size_t q2 = 0; q2 < h->ev_chunk.size() && ok; ++q2) ok = hipEventCreateWithFlags(&h->ev_chunk[q2], hipEventDisableTiming) == hipSuccess;
+            if (!ok) { gmpe_destroy(h); return fail(GMPE_ERR_HIP, "split path: could not create the side streams / events"); }
         }
     }
     const size_t stream_f4 = (size_t)G * h->A * ((size_t)E * E / 4 + 2 * (size_t)E);
@@ -425,6 +440,12 @@ int gmpe_debug_stamps(gmpe_handle* h, unsigned long long* host_dst, int64_t max_
 
 int gmpe_destroy(gmpe_handle* h) {
     if (h) { for (auto& g : h->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); } h->graphs.clear(); if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream); h->cap_stream = nullptr; }
+    if (h) {
+        for (hipStream_t s : {h->env_st[0], h->env_st[1], h->exp_st}) if (s) (void)hipStreamDestroy(s);
+        for (hipEvent_t e : {h->ev_fork, h->ev_join[0], h->ev_join[1], h->ev_join[2]}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : h->ev_chunk) if (e) (void)hipEventDestroy(e);
+        h->ev_chunk.clear();
+    }
     if (!h) return GMPE_OK;
     (void)hipSetDevice(h->device);
     for (void* q : h->allocs) (void)hipFree(q);
@@ -475,6 +496,7 @@ static void fill_params(const gmpe_handle* h, KParams& p, int G) {
     p.spec = h->spec;
     p.stamps = h->stamps;
     p.K = 1; p.S = 1; p.num_slots = 1;
+    p.env_lo = 0; p.env_hi = h->c.num_envs;
     p.m_E = magic_of(p.E); p.m_AE = magic_of(p.A * p.E); p.m_EE = magic_of(p.E * p.E); p.m_nq = magic_of(p.E * p.E / 4);
     p.m_2E = magic_of(2 * p.E); p.m_pe = magic_of(p.A * p.E * 2); p.m_AD = magic_of(p.A * p.D); p.m_A = magic_of(p.A);
     p.m_L = magic_of(p.L); p.m_O = magic_of(p.O);
@@ -486,7 +508,7 @@ static void fill_params(const gmpe_handle* h, KParams& p, int G) {
 static int ap_of(const gmpe_handle* h) { return (h->A == h->L && h->O == 0 && (h->A == 10 || h->A == 3)) ? h->A : 0; }   // exact-size instantiations of the common cases (A = L, no obstacles)
 static void dispatch_env(const gmpe_handle* h, int block, int ap, int fl, hipStream_t st, const KParams& p) {
     const size_t lds = lds_bytes(p.G, h->A, h->E, h->D, h->c.num_walls);
-    const dim3 grid((h->c.num_envs + p.G - 1) / p.G);
+    const dim3 grid((p.env_hi - p.env_lo + p.G - 1) / p.G);
     switch (sc_of(h->c)) {
         case SC_NAV: launch_env<SC_NAV>(block, ap, fl, grid, lds, st, p); break;
         case SC_NAV_WALLS: launch_env<SC_NAV_WALLS>(block, ap, fl, grid, lds, st, p); break;
@@ -497,6 +519,40 @@ static void dispatch_env(const gmpe_handle* h, int block, int ap, int fl, hipStr
     }
 }
 
+// Split big-E path: one step as a software pipeline over env chunks —
+//   env_st[c & 1]:  k_env(chunk c) -> compact matrices into the scratch          (latency-bound, ~10 % of HBM)
+//   exp_st:         k_adj_expand(chunk c): scratch -> adj [N,A,E,E]               (HBM-bound fill, 6.5-6.9 TB/s alone)
+// expand(c) waits for k_env(c) through an event, so the expansion of one chunk overlaps the fused kernel of the next; two env
+// streams let one chunk's last, partly filled round of tiles overlap the next chunk's first. Fork from / join into the caller's
+// stream. (Pipelining ACROSS steps as well — expansion of step k under k_env of step k+1, two scratch buffers — was built and
+// measured slower: with both kernels resident all the time the expansion runs at half speed, c4 1563 vs 1252 us; profiles/README.md.)
+static int split_pipeline(gmpe_handle* h, int mode, KParams& p, float* adj_full, hipStream_t st) {
+    const uint32_t EE = (uint32_t)h->E * h->E;
+    const int N = h->c.num_envs, C = h->chunks;
+    const int per = ((N + C - 1) / C + h->G - 1) / h->G * h->G;              // envs per chunk, a whole number of tiles
+    const int fl = (mode == MODE_STEP && !h->nt && !h->ablate && h->spec) ? 1 : 0;
+    p.o.adj = h->adj_scratch; p.o.adj_compact = 1;
+    HIPCHK(hipEventRecord(h->ev_fork, st));
+    for (hipStream_t s : {h->env_st[0], h->env_st[1], h->exp_st}) HIPCHK(hipStreamWaitEvent(s, h->ev_fork, 0));
+    for (int c = 0; c < C; ++c) {
+        const int lo = c * per, hi = lo + per < N ? lo + per : N;
+        if (lo >= hi) break;
+        hipStream_t se = h->env_st[c & 1];
+        p.env_lo = lo; p.env_hi = hi;
+        dispatch_env(h, h->block, ap_of(h), fl, se, p);
+        HIPCHK(hipEventRecord(h->ev_chunk[c], se));
+        HIPCHK(hipStreamWaitEvent(h->exp_st, h->ev_chunk[c], 0));
+        const int gy = hi - lo < 1024 ? hi - lo : 1024;
+        if ((EE & 3) == 0) hipLaunchKernelGGL(k_adj_expand, dim3(((uint32_t)h->A * (EE / 4) + 255) / 256, gy), dim3(256), 0, h->exp_st,
+                                              h->adj_scratch, adj_full, lo, hi, EE / 4, h->A, magic_of(EE / 4));
+        else hipLaunchKernelGGL(k_adj_expand1, dim3(((uint32_t)h->A * EE + 255) / 256, gy), dim3(256), 0, h->exp_st, h->adj_scratch, adj_full, lo, hi, EE, h->A);
+    }
+    int q = 0;
+    for (hipStream_t s : {h->env_st[0], h->env_st[1], h->exp_st}) { HIPCHK(hipEventRecord(h->ev_join[q], s)); HIPCHK(hipStreamWaitEvent(st, h->ev_join[q], 0)); ++q; }
+    HIPCHK(hipGetLastError());
+    return GMPE_OK;
+}
+
 static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* onehot, const uint8_t* mask,
                   const gmpe_outputs* out, void* stream) {
     if (!h) return fail(GMPE_ERR_INVALID_ARG, "null handle");
@@ -504,9 +560,6 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
     fill_params(h, p, h->G);
     if (out) p.o = *out;
     p.act = act; p.onehot = onehot; p.mask = mask; p.mode = mode;
-    // split path: the fused kernel writes the env's single matrix into the scratch, k_adj_expand makes the A copies
-    float* adj_full = nullptr;
-    if (h->split && p.o.adj && !p.o.adj_compact) { adj_full = p.o.adj; p.o.adj = h->adj_scratch; p.o.adj_compact = 1; }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -517,17 +570,14 @@ static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* one
         e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1];
         HIPCHK(hipEventRecord(e0, st));
     }
-    const int fl = (mode == MODE_STEP && !h->nt && !h->ablate && h->spec) ? 1 : 0;   // steady-state instantiation (flags folded)
-    dispatch_env(h, h->block, ap_of(h), fl, st, p);
-    if (adj_full) {
-        const uint32_t EE = (uint32_t)h->E * h->E, N = (uint32_t)h->c.num_envs;
-        if ((EE & 3) == 0) {
-            const uint32_t total4 = N * (EE / 4);
-            hipLaunchKernelGGL((k_adj_expand<4>), dim3((total4 + 255) / 256), dim3(256), 0, st, h->adj_scratch, adj_full, total4, EE / 4, h->A);
-        } else {
-            const uint32_t total = N * EE;
-            hipLaunchKernelGGL(k_adj_expand1, dim3((total + 255) / 256), dim3(256), 0, st, h->adj_scratch, adj_full, total, EE, h->A);
-        }
+    if (h->split && p.o.adj && !p.o.adj_compact) {
+        // the fused kernel writes the env's single matrix into the scratch, k_adj_expand makes the A copies (chunk pipeline)
+        float* adj_full = p.o.adj;
+        const int rc = split_pipeline(h, mode, p, adj_full, st);
+        if (rc) return rc;
+    } else {
+        const int fl = (mode == MODE_STEP && !h->nt && !h->ablate && h->spec) ? 1 : 0;   // steady-state instantiation (flags folded)
+        dispatch_env(h, h->block, ap_of(h), fl, st, p);
     }
     HIPCHK(hipGetLastError());
     if (h->timing && !h->capturing) { HIPCHK(hipEventRecord(e1, st)); h->ev_used += 2; }
@@ -587,6 +637,7 @@ int gmpe_step_many_prepare(gmpe_handle* h, const int32_t* actions_dev, int32_t n
     if (!h || !actions_dev || num_steps < 1 || num_action_sets < 1) return fail(GMPE_ERR_INVALID_ARG, "gmpe_step_many_prepare: bad arguments");
     gmpe_outputs o; memset(&o, 0, sizeof o); if (out) o = *out;
     if (find_graph(h, actions_dev, num_steps, num_action_sets, o) >= 0) return GMPE_OK;
+    if (h->split) return GMPE_OK;                                 // the split path forks onto side streams per step: not recorded, gmpe_step_many loops
     HIPCHK(hipSetDevice(h->device));
     if (!h->cap_stream) HIPCHK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
     if (h->graphs.size() >= 4) {                                  // small cache: drop the oldest
@@ -623,6 +674,7 @@ int gmpe_step_many(gmpe_handle* h, const int32_t* actions_dev, int32_t num_steps
 int gmpe_step_many_launches(gmpe_handle* h, const int32_t* actions_dev, int32_t num_steps, int32_t num_action_sets,
                             const gmpe_outputs* out, void* stream) {
     if (!h || !actions_dev || num_steps < 0 || num_action_sets < 1) return fail(GMPE_ERR_INVALID_ARG, "gmpe_step_many_launches: bad arguments");
+    if (num_steps == 0) return GMPE_OK;
     if (!h->timing) {                                             // per-launch event pairs need individual launches
         gmpe_outputs o; memset(&o, 0, sizeof o); if (out) o = *out;
         const int q = find_graph(h, actions_dev, num_steps, num_action_sets, o);

@@ -161,3 +161,27 @@ def test_full_size_c5_shard_with_oracle_slice():
     t = eng.tuning()
     assert t["nt"] == 1 or t["split"] == 1
     _graph_invariants(o, 64, 128, 8)
+
+
+@pytest.mark.parametrize("chunks", [1, 3, 8])
+def test_split_pipeline_across_steps_equals_step_loop(monkeypatch, chunks):
+    """gmpe_step_many on the split path (one chunk pipeline per step, any chunk count): same final outputs and state as one
+    gmpe_step per step."""
+    import torch
+    _knobs(monkeypatch, split=1, chunks=chunks)
+    cfg = gmpe.make_config(scenario_name="navigation_graph", num_envs=37, num_agents=12, num_obstacles=3, num_walls=4, world_size=5.0,
+                           episode_length=6, seed=97)
+    e1, e2 = _engine(cfg), _engine(cfg)
+    assert e1.tuning()["split"] == 1
+    e1.reset(); e2.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    acts = torch.randint(0, cfg.n_actions, (5, 37, 12), generator=g, device="cuda", dtype=torch.int32)
+    for K in (1, 2, 9, 14):
+        for k in range(K):
+            o1 = e1.step(acts[k % 5])
+        o2 = e2.step_many(acts, K)
+        torch.cuda.synchronize()
+        for key in ("obs", "agent_id", "node_obs", "adj", "reward", "done", "info"):
+            assert torch.equal(getattr(o1, key), getattr(o2, key)), (K, key)
+        _compare_state(e1, e2, "K=%d" % K)
+    e1.check_errors(); e2.check_errors()
