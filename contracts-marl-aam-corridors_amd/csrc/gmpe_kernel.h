@@ -632,7 +632,7 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
 // FL = 1: the steady-state instantiation — step mode, wave specialisation on, ordinary stores, no ablation — with those run-time
 // flags folded (selected by the host when they hold; everything else takes FL = 0).
 template <int BLOCK, int AP, int SC, int FL>
-__global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL == 2 && BLOCK > 64 ? 4 : (AP > 0 && BLOCK > 64 ? (sc_rotfam(SC) ? 3 : 4) : GMPE_MIN_WAVES_NOWALLS)))) void k_env(const KParams p_arg) {
+__global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL == 2 && BLOCK > 64 ? (SC == SC_ROT ? 3 : 4) : (AP > 0 && BLOCK > 64 ? (sc_rotfam(SC) ? 3 : 4) : GMPE_MIN_WAVES_NOWALLS)))) void k_env(const KParams p_arg) {
     const KParams& p = p_arg;
     constexpr bool WALLS = SC == SC_NAV_WALLS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1237,7 +1237,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
                     }
                 }
                 STAMP(7);
-                if (spec) {                                                 // wave-local: the rows were written by this wave's own lanes
+                if (spec && !ROLL) {                                        // wave-local: the rows were written by this wave's own lanes
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1308,7 +1308,9 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
         // ---- small outputs: obs staging rows and agent ids. In a specialised tile wave 0 has already stored them
         // (it wrote the staging rows itself), so nobody waits behind the barrier for the streaming waves.
         STAMP(11);
-        if (!spec) {
+        // (rollouts: wave 0's per-step work is the critical path of the whole kernel, so there the 3 us of obs stores — queued behind
+        // the streaming waves' traffic — are taken off it and every thread stores a few elements after the step's closing barrier)
+        if (!spec || ROLL) {
             if (out.obs) {
                 float* dst = out.obs + (size_t)n0 * A * D;
                 const int AD = A * D;

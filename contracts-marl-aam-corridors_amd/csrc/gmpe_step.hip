@@ -144,6 +144,7 @@ struct gmpe_handle {
     int ablate = 0;
     int nt = 0;
     int spec = 0;
+    int ap = 0;                      // exact-size instantiation in use (0: run-time sizes)
     int split = 0;                   // big-E path: k_env -> compact scratch -> k_adj_expand
     int roll = 1;                    // gmpe_step_many runs the persistent rollout kernel
     int G_roll = 1, block_roll = 256;   // tile shape of the rollout kernel (its own register budget -> its own residency)
@@ -324,7 +325,9 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) dev_cus = prop.multiProcessorCount; }
     int Gmax = 64 / h->A; if (Gmax < 1) Gmax = 1; if (Gmax > (int)N) Gmax = (int)N;
     while (Gmax > 1 && lds_bytes(Gmax, h->A, E, h->D, cfg->num_walls) > 48 * 1024) --Gmax;
-    const int ap_sel = (h->A == h->L && h->O == 0 && (h->A == 10 || h->A == 3)) ? h->A : 0;
+    int ap_sel = (h->A == h->L && h->O == 0 && (h->A == 10 || h->A == 3)) ? h->A : 0;   // exact-size instantiations of the common cases (A = L, no obstacles)
+    if (getenv("GMPE_AP") && atoi(getenv("GMPE_AP")) == 0) ap_sel = 0;                    // tuning: run-time sizes
+    h->ap = ap_sel;
     int G = 0, block_sel = 0;
     if (!env_g && !env_block) {
         int G0 = (int)((N + 4 * (size_t)dev_cus - 1) / (4 * (size_t)dev_cus));
@@ -505,7 +508,7 @@ static void fill_params(const gmpe_handle* h, KParams& p, int G) {
     p.m_W = magic_of(p.E * (p.E - 1) / 2); p.m_Sx = magic_of((p.E & 1) ? (p.E - 1) / 2 : p.E - 1);      // distance_pass: pairs per env, inner divisor
     p.m_FW = magic_of(p.A * (p.A - 1) / 2 + p.A * p.O);
 }
-static int ap_of(const gmpe_handle* h) { return (h->A == h->L && h->O == 0 && (h->A == 10 || h->A == 3)) ? h->A : 0; }   // exact-size instantiations of the common cases (A = L, no obstacles)
+static int ap_of(const gmpe_handle* h) { return h->ap; }
 static void dispatch_env(const gmpe_handle* h, int block, int ap, int fl, hipStream_t st, const KParams& p) {
     const size_t lds = lds_bytes(p.G, h->A, h->E, h->D, h->c.num_walls);
     const dim3 grid((p.env_hi - p.env_lo + p.G - 1) / p.G);

@@ -326,5 +326,8 @@ def test_kernels_do_not_spill():
     txt = out.stdout + out.stderr
     names = re.findall(r"Function Name: (\S*k_env\S*)", txt)
     scratch = re.findall(r"Function Name: \S*k_env\S*.*?ScratchSize \[bytes/lane\]: (\d+)", txt, flags=re.S)
-    assert len(names) >= 60 and len(scratch) == len(names)      # 6 scenario variants x (3 tile shapes x 3 exact sizes + the steady-state one)
-    assert all(int(x) == 0 for x in scratch), list(zip(names, scratch))
+    assert len(names) >= 72 and len(scratch) == len(names)      # 6 scenario variants x (3 tile shapes x 3 exact sizes + the steady-state one + 2 rollout ones)
+    # Zero everywhere except the exact-size July instantiations at their 128-VGPR cap: 3 dwords in a cold path, measured FASTER than the
+    # spill-free alternatives (c3 closed loop 26.27 us vs 26.95 us run-time sizes / 27.05 us at three waves per SIMD, profiles/README.md).
+    bad = [(n, x) for n, x in zip(names, scratch) if int(x) > (16 if "ELi10ELi2ELi" in n else 0)]
+    assert not bad, bad

@@ -7,14 +7,18 @@ import gmpe
 from gmpe import _lib
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libgmpe_stamps.so")
 from gmpe.engine import GmpeEngine
+import bench
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
-scen = "navigation_graph" if wl == "c2" else "nav_metered_one_goal_graph_rotate_tube_july"
-cfg = gmpe.make_config(scenario_name=scen, num_envs=4096, num_agents=10, seed=1234)
+W = bench.WORKLOADS[wl]
+N = int(sys.argv[2]) if len(sys.argv) > 2 else min(W["envs"], 4096)
+cfg = gmpe.make_config(scenario_name=W["scenario_name"], num_envs=N, num_agents=W["num_agents"], num_obstacles=W["num_obstacles"],
+                       num_walls=W["num_walls"], world_size=W["world_size"], episode_length=W["episode_length"], seed=1234)
 eng = GmpeEngine(cfg)
+print("tuning", eng.tuning())
 eng.reset()
 g = torch.Generator(device="cuda"); g.manual_seed(1)
-acts = torch.randint(0, cfg.n_actions, (40, 4096, 10), generator=g, device="cuda", dtype=torch.int32)
-for k in range(30):
+acts = torch.randint(0, cfg.n_actions, (40, N, cfg.num_agents), generator=g, device="cuda", dtype=torch.int32)
+for k in range(20):
     eng.step(acts[k])
 torch.cuda.synchronize()
 lib = _lib.load()
