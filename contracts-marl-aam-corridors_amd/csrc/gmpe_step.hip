@@ -83,6 +83,84 @@ __global__ __launch_bounds__(256) void k_edge_write(const float* __restrict__ ad
     }
 }
 
+// The same edge set from the COMPACT adjacency [N,E,E] (one matrix per env; the A ego copies of the reference are aliases of it,
+// …_july.py:1625, 1647-1648): each env's matrix is read ONCE per pass instead of A times and the A id-shifted copies of its edge list
+// are emitted from registers — identical output to k_edge_count / k_edge_scan / k_edge_write on the materialised [N*A,E,E] tensor.
+// Two launches: (1) per-env counts + per-block totals (a wave per env, 4 envs per block); (2) each block re-reduces the totals of the
+// blocks before it (<= N/4 values, L2-resident; no atomics, no scan launch), adds its own earlier waves and its waves write. I64: int64 ids.
+__global__ __launch_bounds__(256) void k_edgec_count(const float* __restrict__ adj, int N, int EE, float d, int inclusive,
+                                                     int32_t* __restrict__ counts, int32_t* __restrict__ btot) {
+    __shared__ int wc[4];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + w;                                     // one wave per env
+    int c = 0;
+    if (n < N) {
+        const float* g = adj + (size_t)n * EE;
+        for (int q0 = 0; q0 < EE; q0 += 512) {                            // 8 independent loads per lane in flight (the pass is latency-bound)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int q = q0 + u * 64 + lane; v[u] = q < EE ? g[q] : 0.0f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c += __popcll(__ballot(q0 + u * 64 + lane < EE && edge_pred(v[u], d, inclusive)));
+        }
+        if (lane == 0) counts[n] = c;
+    }
+    if (lane == 0) wc[w] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) btot[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+template <bool I64>
+__global__ __launch_bounds__(256) void k_edgec_write(const float* __restrict__ adj, int N, int A, int E, float d, int inclusive,
+                                                     const int32_t* __restrict__ counts, const int32_t* __restrict__ btot,
+                                                     void* __restrict__ edge_index, float* __restrict__ edge_attr, long long cap, int32_t* __restrict__ total) {
+    __shared__ long long red[4];
+    __shared__ int cnt[4];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, EE = E * E;
+    const int n = blockIdx.x * 4 + w;
+    long long part = 0;
+    for (int q = threadIdx.x; q < (int)blockIdx.x; q += 256) part += btot[q];
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+    if (lane == 0) { red[w] = part; cnt[w] = n < N ? counts[n] : 0; }
+    __syncthreads();
+    long long base = red[0] + red[1] + red[2] + red[3];                  // edges of ONE copy of every env before this block
+    for (int k = 0; k < w; ++k) base += cnt[k];
+    const int c = cnt[w];
+    if (n < N) {
+        const float* g = adj + (size_t)n * EE;
+        const long long b0 = base * A;                                    // (batch,row,col) order: the A copies of env n follow each other
+        int run = 0;
+        for (int q0 = 0; q0 < EE; q0 += 512) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int q = q0 + u * 64 + lane; v[u] = q < EE ? g[q] : 0.0f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + u * 64 + lane;
+                const bool f = q < EE && edge_pred(v[u], d, inclusive);
+                const unsigned long long bal = __ballot(f);
+                if (f) {
+                    const int pe = run + __popcll(bal & ((1ull << lane) - 1ull));
+                    const int r = q / E, cc = q - r * E;
+                    for (int a = 0; a < A; ++a) {
+                        const long long pos = b0 + (long long)a * c + pe;
+                        if (pos < cap) {
+                            const long long id0 = ((long long)n * A + a) * E;
+                            if (I64) { static_cast<long long*>(edge_index)[pos] = id0 + r; static_cast<long long*>(edge_index)[cap + pos] = id0 + cc; }
+                            else { static_cast<int32_t*>(edge_index)[pos] = (int32_t)(id0 + r); static_cast<int32_t*>(edge_index)[cap + pos] = (int32_t)(id0 + cc); }
+                            edge_attr[pos] = v[u];
+                        }
+                    }
+                }
+                run += __popcll(bal);
+            }
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {              // wave 3 of the last block: everything before it + its own env
+        const long long t = (base + c) * A;
+        *total = t > 0x7fffffffLL ? 0x7fffffff : (int32_t)t;
+    }
+}
+
 // GraphReplayBuffer.insert's mask rules (onpolicy/utils/graph_buffer.py:223-251, graph_mpe_runner.py:85-90, 395-405) from the step's
 // dones: masks = 0 where done; active_masks = 0 where done unless every agent of the env is done. One thread per (env, agent).
 __global__ __launch_bounds__(256) void k_masks(const uint8_t* __restrict__ done, int N, int A, float* __restrict__ masks, float* __restrict__ active) {
@@ -159,6 +237,8 @@ struct gmpe_handle {
     hipEvent_t region_ev[2] = {nullptr, nullptr};
     int32_t* edge_ws = nullptr;      // [cap_graphs] counts | [cap_graphs] offsets | [cap_graphs/1024+2] chunk sums
     size_t edge_ws_graphs = 0;
+    int32_t* edgec_ws = nullptr;     // compact-adjacency edge kernels: [N] counts | [N/4] block totals
+    size_t edgec_ws_n = 0;
     // hipGraphs of open-loop rollouts (gmpe_step_many_prepare): K kernel nodes replayed by one hipGraphLaunch
     struct StepGraph { const int32_t* actions; int32_t K, S; gmpe_outputs out; hipGraph_t graph; hipGraphExec_t exec; };
     std::vector<StepGraph> graphs;
@@ -454,6 +534,7 @@ int gmpe_destroy(gmpe_handle* h) {
     for (void* q : h->allocs) (void)hipFree(q);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     if (h->edge_ws) (void)hipFree(h->edge_ws);
+    if (h->edgec_ws) (void)hipFree(h->edgec_ws);
     for (hipEvent_t e : h->region_ev) if (e) (void)hipEventDestroy(e);
     delete h;
     return GMPE_OK;
@@ -719,6 +800,31 @@ int gmpe_edges_from_adj(gmpe_handle* h, const float* adj_dev, int32_t batch, int
     hipLaunchKernelGGL(k_edge_scan, dim3(nchunks), dim3(1024), 0, st, counts, batch, offsets, n_edges_dev);
     hipLaunchKernelGGL(k_edge_write, dim3((batch + 3) / 4), dim3(256), 0, st, adj_dev, batch, num_nodes, max_edge_dist, inclusive, offsets,
                        edge_index_dev, edge_attr_dev, cap);
+    HIPCHK(hipGetLastError());
+    return GMPE_OK;
+}
+
+int gmpe_edges_from_adj_compact(gmpe_handle* h, const float* adj_compact_dev, int32_t num_envs, int32_t copies, int32_t num_nodes,
+                                float max_edge_dist, int32_t inclusive, int32_t index64, void* edge_index_dev, float* edge_attr_dev,
+                                int64_t cap, int32_t* n_edges_dev, void* stream) {
+    if (!h || !adj_compact_dev || !edge_index_dev || !edge_attr_dev || !n_edges_dev) return fail(GMPE_ERR_INVALID_ARG, "gmpe_edges_from_adj_compact: null argument");
+    if (num_envs < 1 || copies < 1 || num_nodes < 1 || cap < 0) return fail(GMPE_ERR_INVALID_ARG, "gmpe_edges_from_adj_compact: bad sizes");
+    if (!index64 && (int64_t)num_envs * copies * num_nodes > INT32_MAX) return fail(GMPE_ERR_INVALID_ARG, "gmpe_edges_from_adj_compact: node ids overflow int32 (use index64)");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t need = (size_t)num_envs + (size_t)(num_envs + 3) / 4 + 2;
+    if (h->edgec_ws_n < need) {                              // workspace grows on first use only
+        if (h->edgec_ws) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(h->edgec_ws)); h->edgec_ws = nullptr; }
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->edgec_ws), sizeof(int32_t) * need));
+        h->edgec_ws_n = need;
+    }
+    int32_t* counts = h->edgec_ws; int32_t* btot = h->edgec_ws + num_envs;
+    const int nb = (num_envs + 3) / 4, EE = num_nodes * num_nodes;
+    hipLaunchKernelGGL(k_edgec_count, dim3(nb), dim3(256), 0, st, adj_compact_dev, num_envs, EE, max_edge_dist, inclusive, counts, btot);
+    if (index64) hipLaunchKernelGGL((k_edgec_write<true>), dim3(nb), dim3(256), 0, st, adj_compact_dev, num_envs, copies, num_nodes, max_edge_dist, inclusive,
+                                    counts, btot, edge_index_dev, edge_attr_dev, (long long)cap, n_edges_dev);
+    else hipLaunchKernelGGL((k_edgec_write<false>), dim3(nb), dim3(256), 0, st, adj_compact_dev, num_envs, copies, num_nodes, max_edge_dist, inclusive,
+                            counts, btot, edge_index_dev, edge_attr_dev, (long long)cap, n_edges_dev);
     HIPCHK(hipGetLastError());
     return GMPE_OK;
 }

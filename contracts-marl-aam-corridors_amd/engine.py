@@ -214,6 +214,21 @@ class GmpeEngine(object):
         m = int(ne.item())
         return ei[:, :min(m, cap)], ea[:min(m, cap)], m
 
+    def edges_from_adj_compact(self, adj_compact, copies, max_edge_dist, inclusive=False, cap=None, index64=True):
+        """process_adj's edge set (gnn_new.py:329-358) for the [N*copies, E, E] batch the runner feeds the GNN, computed from the
+        compact [N, E, E] adjacency: -> (edge_index [2, M] int64 (or int32), edge_attr [M], M)."""
+        adj = adj_compact.reshape(-1, adj_compact.shape[-2], adj_compact.shape[-1]).contiguous()
+        N, E = adj.shape[0], adj.shape[-1]
+        cap = int(cap if cap is not None else N * copies * E * E)
+        ei = torch.empty((2, cap), dtype=torch.int64 if index64 else torch.int32, device=self.device)
+        ea = torch.empty((cap,), dtype=torch.float32, device=self.device)
+        ne = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.gmpe_edges_from_adj_compact(self.h, adj.data_ptr(), N, int(copies), E, float(max_edge_dist), int(inclusive),
+                                                        int(bool(index64)), ei.data_ptr(), ea.data_ptr(), cap, ne.data_ptr(), self._stream()),
+                   "gmpe_edges_from_adj_compact")
+        m = int(ne.item())
+        return ei[:, :min(m, cap)], ea[:min(m, cap)], m
+
     def masks_from_dones(self, done, masks, active_masks):
         """masks / active_masks (f32 [N,A,...], contiguous, N*A elements) from a uint8 [N,A] done tensor, one tiny kernel."""
         _lib.check(self.lib.gmpe_masks_from_dones(self.h, done.data_ptr(), masks.data_ptr() if masks is not None else None,

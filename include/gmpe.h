@@ -253,6 +253,15 @@ int gmpe_edges_from_adj(gmpe_handle* h, const float* adj_dev, int32_t batch, int
                         float max_edge_dist, int32_t inclusive, int32_t* edge_index_dev,
                         float* edge_attr_dev, int32_t cap, int32_t* n_edges_dev, void* stream);
 
+/* The same edge set computed from the COMPACT adjacency the engine writes with gmpe_outputs.adj_compact (adj_compact_dev: f32
+ * [num_envs,E,E]): the `copies` (= A) per-agent graphs of an env are identical up to the id shift, so each matrix is read once and
+ * the A copies of its edge list are emitted — output identical to gmpe_edges_from_adj on the materialised [num_envs*copies,E,E]
+ * tensor, batch b = env*copies + copy. index64 != 0: edge_index is int64 [2,cap] (what torch.nonzero / PyG message passing use,
+ * gnn_new.py:329-358), else int32. n_edges saturates at INT32_MAX. */
+int gmpe_edges_from_adj_compact(gmpe_handle* h, const float* adj_compact_dev, int32_t num_envs, int32_t copies, int32_t num_nodes,
+                                float max_edge_dist, int32_t inclusive, int32_t index64, void* edge_index_dev, float* edge_attr_dev,
+                                int64_t cap, int32_t* n_edges_dev, void* stream);
+
 /* Rollout-buffer masks from a step's dones (GraphReplayBuffer.insert: onpolicy/utils/graph_buffer.py:223-251 with the runner's
  * rules graph_mpe_runner.py:85-90, 395-405): masks f32 [N,A] = 0 where done; active_masks f32 [N,A] = 0 where done unless all agents of
  * the env are done. Either output may be NULL. */

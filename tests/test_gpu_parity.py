@@ -497,3 +497,35 @@ def test_edges_from_adj_many_graphs_and_caps():
         ei2, ea2, m2 = eng.edges_from_adj(t, 1.0, cap=cap)
         assert m2 == m and ei2.shape[1] == cap
         np.testing.assert_array_equal(_np(ei2), e_ref[:, :cap]); np.testing.assert_array_equal(_np(ea2), w_ref[:cap])
+
+
+@pytest.mark.parametrize("scen,A,O", [("nav_metered_one_goal_graph_rotate_tube_july", 10, 0), ("navigation_graph", 5, 3), ("two_phase_graph", 3, 0)])
+def test_edges_from_compact_adjacency_equal_materialised(scen, A, O):
+    """gmpe_edges_from_adj_compact (each env's matrix read once, A id-shifted copies emitted) == gmpe_edges_from_adj on the materialised
+    [N*A,E,E] tensor == NumPy nonzero, under both threshold rules, int32 and int64 ids, with and without a cap; N not a multiple of 16."""
+    import torch
+    N = 203
+    cfg = gmpe.make_config(scenario_name=scen, num_envs=N, num_agents=A, num_obstacles=O, world_size=3.0, episode_length=6, seed=4)
+    eng = _engine(cfg)
+    eng.reset()
+    g = torch.Generator(); g.manual_seed(2)
+    for t in range(9):
+        o = eng.step(torch.randint(0, cfg.n_actions, (N, A), generator=g, dtype=torch.int32))
+    E = cfg.num_entities
+    full = o.adj.reshape(-1, E, E)
+    compact = o.adj[:, 0].contiguous()
+    for dist, incl in ((1.0, False), (4.82802, True), (0.3, False)):
+        e_ref, w_ref = edges_numpy(_np(full), np.float32(dist), incl)
+        ei, ea, m = eng.edges_from_adj(full, dist, inclusive=incl)
+        for i64 in (True, False):
+            ci, ca, cm = eng.edges_from_adj_compact(compact, A, dist, inclusive=incl, index64=i64)
+            assert cm == m == e_ref.shape[1] and ci.dtype == (torch.int64 if i64 else torch.int32)
+            np.testing.assert_array_equal(_np(ci), e_ref)
+            np.testing.assert_array_equal(_np(ca), w_ref)
+            assert torch.equal(ci.to(torch.int32), ei) and torch.equal(ca, ea)
+        if m == 0:
+            continue
+        cap = max(1, m // 3)
+        ci, ca, cm = eng.edges_from_adj_compact(compact, A, dist, inclusive=incl, cap=cap)
+        assert cm == m and ci.shape[1] == cap
+        np.testing.assert_array_equal(_np(ci), e_ref[:, :cap]); np.testing.assert_array_equal(_np(ca), w_ref[:cap])
