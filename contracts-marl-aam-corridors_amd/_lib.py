@@ -14,7 +14,8 @@ SYMBOLS = ["gmpe_abi_version", "gmpe_last_error", "gmpe_obs_dim", "gmpe_node_fea
            "gmpe_destroy", "gmpe_set_rng_tape", "gmpe_reset", "gmpe_step", "gmpe_step_many", "gmpe_step_many_prepare", "gmpe_step_onehot",
            "gmpe_field_bytes", "gmpe_get_field", "gmpe_set_field", "gmpe_edges_from_adj", "gmpe_masks_from_dones",
            "gmpe_timing_enable", "gmpe_timing_read", "gmpe_timing_mark", "gmpe_timing_region_ms",
-           "gmpe_rollout_steps", "gmpe_get_tuning", "gmpe_step_many_launches", "gmpe_edges_from_adj_compact"]
+           "gmpe_rollout_steps", "gmpe_get_tuning", "gmpe_step_many_launches", "gmpe_edges_from_adj_compact",
+           "gmpe_set_control_override", "gmpe_field_device_ptr"]
 
 
 class GmpeOutputs(C.Structure):
@@ -72,6 +73,8 @@ def load():
     lib.gmpe_edges_from_adj.argtypes = [P, P, C.c_int32, C.c_int32, C.c_float, C.c_int32, P, P, C.c_int32, P, P]
     lib.gmpe_edges_from_adj_compact.argtypes = [P, P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, P, P, C.c_int64, P, P]
     lib.gmpe_masks_from_dones.argtypes = [P, P, P, P, P]
+    lib.gmpe_set_control_override.argtypes = [P, P, P]
+    lib.gmpe_field_device_ptr.argtypes = [P, I, C.POINTER(P)]
     lib.gmpe_timing_enable.argtypes = [P, C.c_int32]
     lib.gmpe_timing_read.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]
     lib.gmpe_timing_mark.argtypes = [P, C.c_int32, P]

@@ -99,6 +99,8 @@ class GmpeConfig(C.Structure):
         ("damping", C.c_double), ("contact_force", C.c_double), ("contact_margin", C.c_double),
         ("wall_contact_force", C.c_double), ("wall_contact_margin", C.c_double),
         ("walls", GmpeWall * MAX_WALLS),
+        ("graph_feat_type", C.c_int32), ("contact_family", C.c_int32),
+        ("agent_size", C.c_double), ("collider_size", C.c_double), ("agent_mass", C.c_double), ("action_force_scale", C.c_double),
     ]
 
     # ---- derived sizes (gmpe_obs_dim / gmpe_num_entities)
@@ -112,7 +114,7 @@ class GmpeConfig(C.Structure):
 
     @property
     def node_feats(self):
-        return 7 if self.scenario in ROT_FAMILY else NODE_FEATS
+        return 7 if (self.scenario in ROT_FAMILY or self.graph_feat_type == 1) else NODE_FEATS
 
 
 def default_walls(world_size, num_walls):
@@ -126,8 +128,15 @@ def make_config(scenario_name="nav_metered_one_goal_graph_rotate_tube_july", dyn
                 num_envs=1, num_agents=3, num_landmarks=None, num_obstacles=0, num_walls=0,
                 world_size=4.0, episode_length=25, max_speed=2.0, collision_rew=5.0,
                 formation_rew=1.0, goal_rew=5.0, collaborative=False, total_actions=5, seed=1,
-                env_id_base=0, walls=None):
-    """Build the POD from keyword arguments with the reference's defaults."""
+                env_id_base=0, walls=None, graph_feat_type="relative", contact_family="multiagent", agent_size=None, collider_size=None,
+                agent_mass=1.0, agent_accel=None):
+    """Build the POD from keyword arguments with the reference's defaults.
+
+    graph_feat_type: 'relative' (default) or 'global' (…_july.py:1672-1691; July / navigation_graph only).
+    contact_family (navigation_graph only): 'multiagent' = multiagent/core.py:542-548, 872-906 (contact 300 / 0.02, walls 220 / 0.024,
+    d_min = COLLISION_DISTANCE, done sides get no agent-agent force) or 'classic' = onpolicy/envs/mpe/core.py:125-130, 273-286
+    (contact 100 / 1e-3 for entities AND walls, d_min = size_a + size_b with agent_size / collider_size, v += F / agent_mass * dt,
+    action force mass * agent_accel (or mass), sensitivity = agent_accel or 5.0 as in the classic _set_action)."""
     if scenario_name not in SCENARIOS:
         raise NotImplementedError("scenario %r is not built by this engine (have: %s)"
                                   % (scenario_name, sorted(SCENARIOS)))
@@ -170,6 +179,27 @@ def make_config(scenario_name="nav_metered_one_goal_graph_rotate_tube_july", dyn
     c.entity_size = 0.06                               # core.py:385
     c.damping, c.contact_force, c.contact_margin = 0.25, 3e2, 2e-2     # core.py:542-547
     c.wall_contact_force, c.wall_contact_margin = 2.2e2, 2.4e-2        # core.py:545, 548
+    if graph_feat_type not in ("relative", "global"):
+        raise NotImplementedError("graph_feat_type %r" % (graph_feat_type,))
+    if graph_feat_type == "global" and scen in ROT_FAMILY:
+        raise NotImplementedError("graph_feat_type='global' is built for the July scenario and navigation_graph only")
+    c.graph_feat_type = 1 if graph_feat_type == "global" else 0
+    if contact_family not in ("multiagent", "classic"):
+        raise NotImplementedError("contact_family %r" % (contact_family,))
+    c.contact_family = 0
+    c.agent_size = float(c.entity_size if agent_size is None else agent_size)
+    c.collider_size = float(c.entity_size if collider_size is None else collider_size)
+    c.agent_mass, c.action_force_scale = 1.0, 1.0
+    if contact_family == "classic":
+        if scen != SCENARIO_NAVIGATION_GRAPH:
+            raise NotImplementedError("contact_family='classic' applies to the force path (navigation_graph)")
+        c.contact_family = 1
+        c.contact_force, c.contact_margin = 1e2, 1e-3                  # onpolicy/envs/mpe/core.py:128-130
+        c.wall_contact_force, c.wall_contact_margin = c.contact_force, c.contact_margin   # get_wall_collision_force uses the same pair (:330-332)
+        c.agent_mass = float(agent_mass)
+        c.action_force_scale = c.agent_mass * float(agent_accel) if agent_accel is not None else c.agent_mass   # :211-213
+        if agent_accel is not None:
+            c.sensitivity = float(agent_accel)
     if walls is None:
         walls = default_walls(c.world_size, c.num_walls)
     if len(walls) != c.num_walls or c.num_walls > MAX_WALLS:
@@ -184,14 +214,10 @@ def make_config(scenario_name="nav_metered_one_goal_graph_rotate_tube_july", dyn
 def config_from_args(args, num_envs=None, env_id_base=0):
     """`args` is the Namespace GraphMPEEnv(args) takes (multiagent/MPE_env.py:56-84)."""
     g = lambda k, d=None: getattr(args, k, d)
-    if g("use_safety_filter", False):
-        raise NotImplementedError("use_safety_filter: the HJ/CBF filter is out of scope (DESIGN.md)")
     if g("num_scripted_agents", 0):
         raise NotImplementedError("scripted agents are not supported")
     if not g("discrete_action", True):
         raise NotImplementedError("only the discrete action space is supported")
-    if g("graph_feat_type", "relative") != "relative":
-        raise NotImplementedError("graph_feat_type='global' is not built")
     if g("formation_type", "point") != "point":
         raise NotImplementedError("formation_type %r" % g("formation_type"))
     return make_config(
@@ -203,7 +229,7 @@ def config_from_args(args, num_envs=None, env_id_base=0):
         max_speed=g("max_speed", 2), collision_rew=g("collision_rew", 5),
         formation_rew=g("formation_rew", 1), goal_rew=g("goal_rew", 5),
         collaborative=g("collaborative", False), total_actions=g("total_actions", 5),
-        seed=g("seed", 1), env_id_base=env_id_base)
+        seed=g("seed", 1), env_id_base=env_id_base, graph_feat_type=g("graph_feat_type", "relative"))
 
 
 # Field table of include/gmpe.h (gmpe_field): name -> (id, dtype, shape-fn(cfg))

@@ -30,6 +30,8 @@ struct KParams {
     const int32_t* act;       // [N,A] or nullptr
     const float* onehot;      // [N,A,n_actions] or nullptr
     const uint8_t* mask;      // reset mask or nullptr
+    const double* ovr;        // safety-filter hook slot: [N,A,2] controls integrated instead of the decoded action, or nullptr
+    const uint8_t* ovr_use;   // [N,A] where to use them (nullptr: everywhere)
     int mode;
     int env_lo, env_hi;       // env range of this launch [lo, hi): the whole batch, or one chunk of the split big-E pipeline
     int A, L, O, E, D, F;     // F = node features per row (8, rot_inv: 7)
@@ -572,7 +574,31 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
             }
         }
     }
-    if (!sc_rotfam(SC) && o.node_obs && !(abl & 2)) {
+    if (!sc_rotfam(SC) && o.node_obs && !(abl & 2) && p.c.graph_feat_type == 1) {
+        // graph_feat_type 'global' (_get_entity_feat_global, …_july.py:1672-1691): row (ego, entity k) = 7 floats [vel, pos, goal, type] in
+        // world coordinates — the same for every ego except that ego i sees agent k's re-drawn velocity iff k reached its goal in this
+        // step and k <= i (ordered-visibility rule). A lane owns one (env, entity) and walks the egos; 28-byte rows: scalar stores.
+        float* base = o.node_obs + (size_t)n0 * A * E * 7;
+        for (int sidx = t0; sidx < Gv * E; sidx += nthr) {
+            const int gg = fdiv(sidx, E, p.m_E), k = sidx - gg * E;
+            if (!l.flags[gg * 4 + 3]) continue;
+            const int ab = gg * A, eb = gg * E;
+            const bool kag = k < A;
+            const int kk = kag ? k : 0;
+            const float kx = (float)l.ex[eb + k], ky = (float)l.ey[eb + k];
+            const float kvox = kag ? (float)l.vox[ab + kk] : 0.0f, kvoy = kag ? (float)l.voy[ab + kk] : 0.0f;
+            const float kvnx = kag ? (float)l.vnx[ab + kk] : 0.0f, kvny = kag ? (float)l.vny[ab + kk] : 0.0f;
+            const bool knew = kag && l.newf[ab + kk] != 0;
+            const float gx = kag ? (float)l.ex[eb + A + kk] : kx, gy = kag ? (float)l.ey[eb + A + kk] : ky;
+            const float typ = kag ? 0.0f : (k < A + L ? 1.0f : 2.0f);
+            for (int ei = 0; ei < A; ++ei) {
+                const bool post = knew && k <= ei;
+                float* dst = base + ((size_t)(gg * A + ei) * E + k) * 7;
+                dst[0] = post ? kvnx : kvox; dst[1] = post ? kvny : kvoy; dst[2] = kx; dst[3] = ky; dst[4] = gx; dst[5] = gy; dst[6] = typ;
+            }
+        }
+    }
+    if (!sc_rotfam(SC) && o.node_obs && !(abl & 2) && p.c.graph_feat_type != 1) {
         // node row (ego, entity k) = 2 float4: [rel_vel, rel_pos] and [rel_goal, occupied, type].
         // A lane owns one (env, entity, half) slot, keeps that entity's data in registers and walks the egos.
         float4* base = reinterpret_cast<float4*>(o.node_obs + (size_t)n0 * A * E * GMPE_NODE_FEATS);
@@ -823,7 +849,9 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
                     const int k = kk < A ? kk : L + kk;                     // entity index of collider kk
                     const double dx = l.ex[gg * E + a] - l.ex[gg * E + k], dy = l.ey[gg * E + a] - l.ey[gg * E + k];
                     const double dist = sqrt(dx * dx + dy * dy);
-                    const double pen = logaddexp0(-(dist - c.sep_dist) / c.contact_margin) * c.contact_margin;
+                    // d_min: multiagent/core.py:880 COLLISION_DISTANCE; classic MPE (onpolicy/envs/mpe/core.py:276, 282) size_a + size_b
+                    const double dmin = c.contact_family ? c.agent_size + (kk < A ? c.agent_size : c.collider_size) : c.sep_dist;
+                    const double pen = logaddexp0(-(dist - dmin) / c.contact_margin) * c.contact_margin;
                     const int slot = gg * A * C + a * C + kk;
                     Fx[slot] = c.contact_force * dx / dist * pen; Fy[slot] = c.contact_force * dy / dist * pen;
                 }
@@ -835,7 +863,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
                         const int slot = q / NW, w = q - slot * NW;         // slot = tile-level agent index (gg*A + a)
                         const int gg = fdiv(slot, A, p.m_A), a = slot - gg * A;
                         double wx = 0.0, wy = 0.0;
-                        if (!wall_force(c.walls[w], l.ex[gg * E + a], l.ey[gg * E + a], c.entity_size, c.wall_contact_force, c.wall_contact_margin, wx, wy)) { wx = 0.0; wy = 0.0; }
+                        if (!wall_force(c.walls[w], l.ex[gg * E + a], l.ey[gg * E + a], c.contact_family ? c.agent_size : c.entity_size, c.wall_contact_force, c.wall_contact_margin, wx, wy)) { wx = 0.0; wy = 0.0; }
                         l.fw[(size_t)slot * 2 * NW + 2 * w] = wx; l.fw[(size_t)slot * 2 * NW + 2 * w + 1] = wy;   // None -> +0.0: x + 0.0 == x
                     }
                 }
@@ -846,6 +874,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
             double nx = 0, ny = 0, nv2 = 0, nv3 = 0;
             if (ag) {
                 double u0, u1; decode_action<SC>(c, act_idx, u0, u1);
+                if (p.ovr && (!p.ovr_use || p.ovr_use[na])) { u0 = p.ovr[na * 2]; u1 = p.ovr[na * 2 + 1]; }   // safety-filter hook slot (core.py:692-736)
                 nx = v.ex[i]; ny = v.ey[i]; nv2 = v.s2[i]; nv3 = v.s3[i];
                 if (kin) {
                     if (!v.s_old[i]) {                                      // update_agent_state core.py:819-826
@@ -869,9 +898,11 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
                 } else {
                     // force path core.py:766-845: accumulate in the reference's order for this agent — other
                     // entities by ascending index (side b below its own index, side a above), then walls.
-                    double sx = 1.0 * u0, sy = 1.0 * u1;
+                    const bool classic = c.contact_family != 0;             // onpolicy/envs/mpe/core.py constant family (gmpe_config)
+                    const double fsc = classic ? c.action_force_scale : 1.0; // apply_action_force: mass * accel (or mass)
+                    double sx = fsc * u0, sy = fsc * u1;
                     const double* fxg = Fx + (size_t)g * A * C; const double* fyg = Fy + (size_t)g * A * C;
-                    const bool ego_live = v.s_old[i] == 0;                  // done side gets no agent-agent force (899-900)
+                    const bool ego_live = classic || v.s_old[i] == 0;       // done side gets no agent-agent force (899-900); classic MPE has no such rule
                     SWEEP(k, A) {
                         const bool ok = !AP || k < A;
                         const int kc = ok ? k : 0;
@@ -891,7 +922,8 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
                         for (int w = 0; w < c.num_walls; ++w) { sx = sx + fwi[2 * w]; sy = sy + fwi[2 * w + 1]; }
                     }
                     double vx = nv2 * (1 - c.damping), vy = nv3 * (1 - c.damping);
-                    vx += (sx / 1.0) * c.dt; vy += (sy / 1.0) * c.dt;
+                    if (classic) { vx += (sx / c.agent_mass) * c.dt; vy += (sy / c.agent_mass) * c.dt; }
+                    else { vx += (sx / 1.0) * c.dt; vy += (sy / 1.0) * c.dt; }
                     if (c.max_speed > 0) {
                         const double sp = sqrt(vx * vx + vy * vy);
                         if (sp > c.max_speed) { vx = vx / sp * c.max_speed; vy = vy / sp * c.max_speed; }

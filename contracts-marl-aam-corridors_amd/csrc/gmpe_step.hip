@@ -223,6 +223,8 @@ struct gmpe_handle {
     int nt = 0;
     int spec = 0;
     int ap = 0;                      // exact-size instantiation in use (0: run-time sizes)
+    const double* ovr = nullptr;     // safety-filter hook slot (gmpe_set_control_override)
+    const uint8_t* ovr_use = nullptr;
     int split = 0;                   // big-E path: k_env -> compact scratch -> k_adj_expand
     int roll = 1;                    // gmpe_step_many runs the persistent rollout kernel
     int G_roll = 1, block_roll = 256;   // tile shape of the rollout kernel (its own register budget -> its own residency)
@@ -301,7 +303,7 @@ int gmpe_obs_dim(const gmpe_config* c) {
         default: return 13;
     }
 }
-int gmpe_node_feats(const gmpe_config* c) { return c->scenario >= GMPE_SCENARIO_ROT_INV ? 7 : GMPE_NODE_FEATS; }
+int gmpe_node_feats(const gmpe_config* c) { return (c->scenario >= GMPE_SCENARIO_ROT_INV || c->graph_feat_type == 1) ? 7 : GMPE_NODE_FEATS; }
 int gmpe_num_entities(const gmpe_config* c) { return c->num_agents + c->num_landmarks + c->num_obstacles; }
 
 static int field_info(const gmpe_handle* h, int f, void** ptr, size_t* bytes) {
@@ -353,6 +355,10 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
         return fail(GMPE_ERR_UNSUPPORTED, "unknown scenario");
     if ((cfg->scenario != GMPE_SCENARIO_NAVIGATION_GRAPH) == (cfg->dynamics == GMPE_DYN_DOUBLE_INTEGRATOR))
         return fail(GMPE_ERR_UNSUPPORTED, "the tube scenarios are kinematic; navigation_graph is double_integrator");
+    if (cfg->graph_feat_type < 0 || cfg->graph_feat_type > 1 || (cfg->graph_feat_type == 1 && cfg->scenario >= GMPE_SCENARIO_ROT_INV))
+        return fail(GMPE_ERR_UNSUPPORTED, "graph_feat_type: 0 (relative) everywhere, 1 (global) for tube_july / navigation_graph");
+    if (cfg->contact_family < 0 || cfg->contact_family > 1 || (cfg->contact_family == 1 && (cfg->scenario != GMPE_SCENARIO_NAVIGATION_GRAPH || !(cfg->agent_mass > 0))))
+        return fail(GMPE_ERR_UNSUPPORTED, "contact_family 1 (classic MPE) applies to navigation_graph and needs agent_mass > 0");
     if (cfg->dynamics == GMPE_DYN_DOUBLE_INTEGRATOR ? (cfg->n_actions != 5 && cfg->n_actions != 9) : cfg->n_actions != 25)
         return fail(GMPE_ERR_INVALID_ARG, "n_actions does not match the dynamics");
     int ndev = 0;
@@ -549,6 +555,20 @@ int gmpe_set_rng_tape(gmpe_handle* h, const double* tape_dev, int64_t len_per_en
     return GMPE_OK;
 }
 
+int gmpe_set_control_override(gmpe_handle* h, const double* ctrl_dev, const uint8_t* use_dev) {
+    if (!h) return fail(GMPE_ERR_INVALID_ARG, "null handle");
+    h->ovr = ctrl_dev; h->ovr_use = ctrl_dev ? use_dev : nullptr;
+    // recorded rollouts bake the kernel parameters into their nodes: drop them
+    for (auto& g : h->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+    h->graphs.clear();
+    return GMPE_OK;
+}
+int gmpe_field_device_ptr(gmpe_handle* h, int field, void** ptr_out) {
+    if (!h || !ptr_out) return fail(GMPE_ERR_INVALID_ARG, "gmpe_field_device_ptr: null argument");
+    size_t b;
+    return field_info(h, field, ptr_out, &b);
+}
+
 int gmpe_field_bytes(const gmpe_handle* h, int field, size_t* bytes) {
     void* p; return field_info(h, field, &p, bytes);
 }
@@ -581,6 +601,7 @@ static void fill_params(const gmpe_handle* h, KParams& p, int G) {
     p.stamps = h->stamps;
     p.K = 1; p.S = 1; p.num_slots = 1;
     p.env_lo = 0; p.env_hi = h->c.num_envs;
+    p.ovr = h->ovr; p.ovr_use = h->ovr_use;
     p.m_E = magic_of(p.E); p.m_AE = magic_of(p.A * p.E); p.m_EE = magic_of(p.E * p.E); p.m_nq = magic_of(p.E * p.E / 4);
     p.m_2E = magic_of(2 * p.E); p.m_pe = magic_of(p.A * p.E * 2); p.m_AD = magic_of(p.A * p.D); p.m_A = magic_of(p.A);
     p.m_L = magic_of(p.L); p.m_O = magic_of(p.O);

@@ -46,6 +46,7 @@ class GmpeEngine(object):
             done=torch.empty((N, A), dtype=torch.uint8, device=dev),
             info=torch.empty((N, A, len(INFO_KEYS)), dtype=torch.float32, device=dev) if with_info else None)
         self._tape = None
+        self._ovr = None
         self._o = self._pack(self.out)
 
     # ------------------------------------------------------------------ plumbing
@@ -191,6 +192,33 @@ class GmpeEngine(object):
         torch.cuda.synchronize(self.device)
         self._tape = t
         _lib.check(self.lib.gmpe_set_rng_tape(self.h, t.data_ptr(), t.shape[1]), "gmpe_set_rng_tape")
+
+    def set_control_override(self, ctrl=None, use=None):
+        """Safety-filter hook slot (multiagent/core.py:692-736): `ctrl` float64 device tensor [N,A,2] integrated instead of the decoded
+        action wherever `use` (uint8 [N,A]; None = everywhere) is non-zero. None removes the hook. The tensors are read at step time
+        (the engine keeps references)."""
+        if ctrl is None:
+            self._ovr = None
+            _lib.check(self.lib.gmpe_set_control_override(self.h, None, None), "gmpe_set_control_override")
+            return
+        if ctrl.dtype != torch.float64 or tuple(ctrl.shape) != (self.N, self.A, 2) or not ctrl.is_contiguous() or ctrl.device != self.device:
+            raise ValueError("ctrl must be a contiguous float64 device tensor [N, A, 2]")
+        if use is not None and (use.dtype != torch.uint8 or use.numel() != self.N * self.A or not use.is_contiguous() or use.device != self.device):
+            raise ValueError("use must be a contiguous uint8 device tensor [N, A]")
+        self._ovr = (ctrl, use)
+        _lib.check(self.lib.gmpe_set_control_override(self.h, ctrl.data_ptr(), None if use is None else use.data_ptr()), "gmpe_set_control_override")
+
+    def state_tensor(self, name):
+        """Zero-copy torch view of a state field in HBM (gmpe_field_device_ptr), e.g. for an on-device safety filter that reads
+        x / y / s2 / s3 before the step. Same stream as the engine's launches; do not resize or free."""
+        fid, dt, shp = FIELDS[name]
+        p = C.c_void_p()
+        _lib.check(self.lib.gmpe_field_device_ptr(self.h, fid, C.byref(p)), "gmpe_field_device_ptr")
+        shape = tuple(int(x) for x in shp(self.cfg))
+
+        class _Blob(object):
+            __cuda_array_interface__ = {"shape": shape, "typestr": np.dtype(dt).str, "data": (int(p.value), False), "version": 2, "strides": None}
+        return torch.as_tensor(_Blob(), device=self.device)
 
     def check_errors(self):
         e = self.get("error_flags")

@@ -84,6 +84,23 @@ class DeviceRolloutBuffer(object):
         self.step = (t + 1) % self.T
         return self.engine.out
 
+    def insert_external(self, obs, agent_id, node_obs, adj, rewards, dones):
+        """GraphReplayBuffer.insert's env-side arguments for step outputs produced elsewhere (a replayed log, another engine):
+        device or host tensors in the engine's shapes ([N,A,D], [N,A,1], [N,A,E,F], [N,E,E] or [N,A,E,E], [N,A], [N,A] bool/u8).
+        Same slot placement and mask rules as insert_step (graph_buffer.py:223-251, graph_mpe_runner.py:395-405)."""
+        t, e = self.step, self.engine
+        dev = e.device
+        put = lambda dst, src: dst.copy_(torch.as_tensor(src).to(device=dev, dtype=dst.dtype).reshape(dst.shape))
+        put(self.obs[t + 1], obs); put(self.agent_id[t + 1], agent_id); put(self.node_obs[t + 1], node_obs)
+        a = torch.as_tensor(adj)
+        if e.adj_compact and a.dim() == 4:
+            a = a[:, 0]                                   # the A per-agent matrices are one matrix (…_july.py:1625)
+        elif not e.adj_compact and a.dim() == 3:
+            a = a[:, None].expand(-1, e.A, -1, -1)
+        put(self._adj[t + 1], a); put(self.rewards[t], rewards); put(self.dones[t], torch.as_tensor(dones).to(torch.uint8))
+        e.masks_from_dones(self.dones[t], self.masks[t + 1], self.active_masks[t + 1])
+        self.step = (t + 1) % self.T
+
     def collect(self, action_sets, num_steps=None):
         """The runner's collect loop with a fixed action source (graph_mpe_runner.py:57-103: `for step in range(episode_length)`:
         envs.step -> buffer.insert) as ONE launch of the persistent rollout kernel: step k reads action_sets[k % S] and writes slot

@@ -66,7 +66,15 @@ class BatchedGraphMPEVecEnv(object):
     viewer = None
     metadata = {"render.modes": ["human", "rgb_array"]}
 
-    def __init__(self, all_args, num_envs=None, device=0, env_id_base=0, adj_broadcast_view=True, pinned_host=True):
+    def __init__(self, all_args, num_envs=None, device=0, env_id_base=0, adj_broadcast_view=True, pinned_host=True, safety_filter=None):
+        """safety_filter: the hook slot of `World.step`'s safety filter (multiagent/core.py:692-736). A callable
+        `f(engine, actions_dev) -> (ctrl [N,A,2] float64 device tensor, use [N,A] uint8 device tensor or None)` called before every
+        step; where `use` is set the engine integrates `ctrl` instead of the decoded action. The HJ / CBF filter of the reference
+        (safety_filter.py: jax / cvxpy / value-function data) is not built, so `args.use_safety_filter` without a callable raises."""
+        if getattr(all_args, "use_safety_filter", False) and safety_filter is None:
+            raise NotImplementedError("use_safety_filter=True: the HJ/CBF filter is out of scope (DESIGN.md); pass safety_filter=callable "
+                                      "to fill the hook slot")
+        self._safety_filter = safety_filter
         self.cfg = config_from_args(all_args, num_envs=num_envs, env_id_base=env_id_base)
         # The reference's per-agent adj arrays alias ONE E x E matrix per env (SURVEY fact 6), so the
         # engine writes that matrix once and the [N,A,E,E] result is a zero-copy broadcast view.
@@ -139,16 +147,23 @@ class BatchedGraphMPEVecEnv(object):
         if a.ndim == 3:
             if a.shape != (self.num_envs, self.num_agents, self.cfg.n_actions):
                 raise ValueError("actions must be [N=%d, A=%d, %d]" % (self.num_envs, self.num_agents, self.cfg.n_actions))
-            t = torch.as_tensor(a, dtype=torch.float32)
-            self._pending = self.engine.step_onehot(t.to(self.engine.device, non_blocking=True))
+            t = torch.as_tensor(a, dtype=torch.float32).to(self.engine.device, non_blocking=True)
+            self._filter(t)
+            self._pending = self.engine.step_onehot(t)
         elif a.ndim == 2:
             if tuple(a.shape) != (self.num_envs, self.num_agents):
                 raise ValueError("actions must be [N=%d, A=%d]" % (self.num_envs, self.num_agents))
-            t = torch.as_tensor(a).to(dtype=torch.int32)
-            self._pending = self.engine.step(t.to(self.engine.device, non_blocking=True))
+            t = torch.as_tensor(a).to(dtype=torch.int32).to(self.engine.device, non_blocking=True)
+            self._filter(t)
+            self._pending = self.engine.step(t)
         else:
             raise ValueError("actions must be a one-hot [N,A,n_act] or an index [N,A] array")
         self.waiting = True
+
+    def _filter(self, actions_dev):
+        if self._safety_filter is not None:
+            ctrl, use = self._safety_filter(self.engine, actions_dev)
+            self.engine.set_control_override(ctrl, use)
 
     def step_wait(self):
         """-> 7-tuple (obs, agent_id, node_obs, adj, rewards [N,A], dones [N,A] bool, infos)
@@ -160,6 +175,8 @@ class BatchedGraphMPEVecEnv(object):
         self._pending, self.waiting = None, False
         obs, ids, node, adj, rew, done = self._fetch(o, True)    # synchronises the stream
         done = done.astype(bool)
+        if self.cfg.collaborative:
+            rew = rew[..., None]                       # `reward_n = [[reward]] * self.n` (environment.py:1056-1061) stacks to [N, A, 1]
         infos = LazyInfos(o.info.clone(), self.num_envs, self.num_agents, include_min_time=self.cfg.max_speed > 0,
                           include_phase=self.cfg.node_feats == 7)
         return obs, ids, node, adj, rew, done, infos

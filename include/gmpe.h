@@ -19,7 +19,7 @@
  *  - one handle per GPU; handles are not thread-safe.
  *
  * Shapes: N envs, A agents, L landmarks, O obstacles, E = A+L+O graph nodes, F = 8 node features,
- * D = observation width (19 tube_july, 13 navigation_graph, 13 rot_inv); F = 8 (7 for rot_inv).
+ * D = observation width (19 tube_july, 13 navigation_graph, 13 rot_inv); F = 8 (7 for rot_inv and for graph_feat_type 'global').
  */
 #ifndef GMPE_H
 #define GMPE_H
@@ -109,6 +109,16 @@ typedef struct gmpe_config {
     /* force path (core.py:542-548) */
     double damping, contact_force, contact_margin, wall_contact_force, wall_contact_margin;
     gmpe_wall walls[GMPE_MAX_WALLS];
+    /* ---- ABI 2 ---- */
+    int32_t graph_feat_type;            /* 0 'relative' (…_july.py:1694-1771, F = 8); 1 'global' (…_july.py:1672-1691: [vel, pos,
+                                           goal, type] in world coordinates, F = 7; July and navigation_graph only)              */
+    int32_t contact_family;             /* force path constants: 0 = multiagent/core.py:872-906 (d_min = COLLISION_DISTANCE, no force on a
+                                           done side, separate wall constants); 1 = classic MPE, onpolicy/envs/mpe/core.py:273-286
+                                           (d_min = size_a + size_b, every collider side gets its force, walls share the contact
+                                           constants). navigation_graph only                                                      */
+    double agent_size, collider_size;   /* classic: Entity.size of agents / of obstacles (mpe/core.py:44)                          */
+    double agent_mass;                  /* Entity.mass (mpe/core.py:52 initial_mass = 1.0): v += F / mass * dt                     */
+    double action_force_scale;          /* apply_action_force (mpe/core.py:205-214): mass * accel if accel is not None else mass   */
 } gmpe_config;
 
 /* Persistent per-env state, addressable for checkpoint / parity injection. */
@@ -169,7 +179,7 @@ const char* gmpe_last_error(void);
 
 /* Observation width D, node feature count F and node count E for a config (no device needed). */
 int gmpe_obs_dim(const gmpe_config* cfg);
-int gmpe_node_feats(const gmpe_config* cfg);
+int gmpe_node_feats(const gmpe_config* cfg);   /* 8; 7 for the rot_inv family and for graph_feat_type = 1 */
 int gmpe_num_entities(const gmpe_config* cfg);
 
 /* Create the engine on HIP device `device`. Replaces N x `GraphMPEEnv(args)` + `env.seed(seed +
@@ -238,6 +248,18 @@ int gmpe_step_many_prepare(gmpe_handle* h, const int32_t* actions_dev, int32_t n
 /* Same, taking the runner's float one-hot [N,A,n_actions] (graph_mpe_runner.py:375-377); the
  * argmax (np.argmax: first maximum) is fused into the step kernel. */
 int gmpe_step_onehot(gmpe_handle* h, const float* onehot_dev, const gmpe_outputs* out, void* stream);
+
+/* Safety-filter hook slot (multiagent/core.py:505-534, 692-736): in the reference `World.step` hands every agent's raw control
+ * [omega, accel] (or [a_x, a_y]) to `safety_handle.apply_safety_filter` between `get_action()` and `update_agent_state` and
+ * integrates the FILTERED control. The HJ / CBF filter itself is out of scope (value-function data and jax / cvxpy are absent); this
+ * keeps its place in the step: when `ctrl_dev` (f64 [N,A,2], device, caller-owned) is set, agent (n,a) integrates ctrl_dev[n,a,:]
+ * instead of its decoded action wherever `use_dev` (u8 [N,A]; NULL = everywhere) is non-zero — the `filtered` flag of the reference.
+ * Units: the decoded control AFTER the x5 sensitivity (environment.py:460-463), i.e. what `agent.action.u` holds. An external
+ * filter kernel reads the state through gmpe_field_device_ptr and runs on the same stream before gmpe_step. NULL removes the hook. */
+int gmpe_set_control_override(gmpe_handle* h, const double* ctrl_dev, const uint8_t* use_dev);
+/* Device pointer of a state field (layout in gmpe_field), valid for the life of the handle; for on-device consumers such as the
+ * filter above. Reading it is ordered with the engine's launches only through the stream they share. */
+int gmpe_field_device_ptr(gmpe_handle* h, int field, void** ptr_out);
 
 /* Host <-> engine state copies (whole field, `bytes` must equal the field's size). */
 int gmpe_field_bytes(const gmpe_handle* h, int field, size_t* bytes);

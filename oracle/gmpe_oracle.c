@@ -44,6 +44,8 @@ typedef struct gmpo {
     int32_t* error_flags;
     double* dist;                 /* [N,E,E] world.cached_dist_mag incl. in-place masking */
     const double* tape;
+    const double* ovr_ctrl;   /* safety-filter hook slot (multiagent/core.py:692-736): [N,A,2] filtered controls, or NULL */
+    const uint8_t* ovr_use;   /* [N,A] `filtered` flags, NULL = everywhere */
     int64_t tape_len;
 } gmpo;
 
@@ -99,7 +101,7 @@ static inline int is_kinematic(const gmpo* h) { return h->c.dynamics != GMPE_DYN
 static inline int is_rotfam(const gmpe_config* c) { return c->scenario >= GMPE_SCENARIO_ROT_INV; }      /* rot_inv, two_phase, three_phase */
 static inline int is_phasefam(const gmpe_config* c) { return c->scenario == GMPE_SCENARIO_TWO_PHASE || c->scenario == GMPE_SCENARIO_THREE_PHASE; }
 int gmpo_obs_dim(const gmpe_config* c) { return c->scenario == GMPE_SCENARIO_TUBE_JULY ? 19 : (is_phasefam(c) ? 15 : 13); }
-int gmpo_node_feats(const gmpe_config* c) { return is_rotfam(c) ? 7 : 8; }
+int gmpo_node_feats(const gmpe_config* c) { return (is_rotfam(c) || c->graph_feat_type == 1) ? 7 : 8; }
 static inline int is_tube(const gmpe_config* c) { return c->scenario != GMPE_SCENARIO_NAVIGATION_GRAPH; }
 int gmpo_num_entities(const gmpe_config* c) { return c->num_agents + c->num_landmarks + c->num_obstacles; }
 
@@ -191,6 +193,14 @@ int gmpo_set_field(gmpo* h, int f, const void* src, size_t bytes) {
     memcpy(p, src, b); return GMPE_OK;
 }
 int gmpo_set_rng_tape(gmpo* h, const double* tape, int64_t len_per_env) { h->tape = tape; h->tape_len = len_per_env; return GMPE_OK; }
+/* World.step integrates safe_action_list instead of raw_action_list where the filter intervened (core.py:692-736) */
+int gmpo_set_control_override(gmpo* h, const double* ctrl, const uint8_t* use) { h->ovr_ctrl = ctrl; h->ovr_use = ctrl ? use : NULL; return GMPE_OK; }
+static void filtered_control(const gmpo* h, int n, int i, double* u) {
+    if (!h->ovr_ctrl) return;
+    const size_t na = (size_t)n * h->c.num_agents + i;
+    if (h->ovr_use && !h->ovr_use[na]) return;
+    u[0] = h->ovr_ctrl[2 * na]; u[1] = h->ovr_ctrl[2 * na + 1];
+}
 /* world.cached_dist_mag after in-place masking, [N,E,E] */
 int gmpo_get_dist_cache(gmpo* h, double* dst) { memcpy(dst, h->dist, (size_t)h->N * h->E * h->E * 8); return GMPE_OK; }
 
@@ -712,6 +722,17 @@ static double reward_nav(envv* v, int i) {
 static void graph_observation(envv* v, int i, double* node) {
     const int A = v->A, L = v->L, E = v->E;
     if (is_rotfam(&v->h->c)) { node_features_rot(v, i, node); goto mask; }
+    if (v->h->c.graph_feat_type == 1) {                  /* _get_entity_feat_global, …_july.py:1672-1691: [vel, pos, goal, type] in world coordinates */
+        for (int k = 0; k < E; ++k) {
+            double kx, ky, kvx = 0.0, kvy = 0.0; ent_pos(v, k, &kx, &ky);
+            if (k < A) agent_vel(v, k, &kvx, &kvy);
+            double* r = node + 7 * k;
+            r[0] = kvx; r[1] = kvy; r[2] = kx; r[3] = ky;
+            if (k < A) { r[4] = v->lm[2 * k]; r[5] = v->lm[2 * k + 1]; r[6] = 0.0; }
+            else { r[4] = kx; r[5] = ky; r[6] = k < A + L ? 1.0 : 2.0; }
+        }
+        goto mask;
+    }
     {
     double evx, evy; agent_vel(v, i, &evx, &evy);
     const double px = v->x[i], py = v->y[i];
@@ -935,7 +956,7 @@ static int env_step(envv* v, const int32_t* act, double* obs, int32_t* ids, doub
     if (is_kinematic(h)) {                       /* World.step -> update_agent_state (core.py:819-826) */
         for (int i = 0; i < A; ++i) {
             if (v->status[i]) continue;
-            double u[2]; decode_action(c, act[i], u);
+            double u[2]; decode_action(c, act[i], u); filtered_control(h, n, i, u);
             double s[4] = {v->x[i], v->y[i], v->s2[i], v->s3[i]};
             gmpo_kinematic_step(s, u[0], u[1], c->dt, c->v_min, c->v_max, &v->p_dist[i], &v->time[i]);
             v->x[i] = s[0]; v->y[i] = s[1]; v->s2[i] = s[2]; v->s3[i] = s[3];
@@ -943,15 +964,22 @@ static int env_step(envv* v, const int32_t* act, double* obs, int32_t* ids, doub
     } else {                                     /* force path on agents+landmarks+obstacles */
         double pos[GMPE_MAX_ENTITIES * 2], vel[GMPE_MAX_ENTITIES * 2], F[GMPE_MAX_AGENTS * 2], ms[GMPE_MAX_ENTITIES];
         uint8_t mov[GMPE_MAX_ENTITIES], col[GMPE_MAX_ENTITIES];
+        const int classic = c->contact_family == 1;          /* onpolicy/envs/mpe/core.py constants: d_min = size_a + size_b, per-entity mass */
+        double size[GMPE_MAX_ENTITIES], mass[GMPE_MAX_ENTITIES];
         for (int k = 0; k < E; ++k) {
+            size[k] = k < A ? c->agent_size : c->collider_size; mass[k] = k < A ? c->agent_mass : 1.0;
             ent_pos(v, k, &pos[2 * k], &pos[2 * k + 1]);
             vel[2 * k] = k < A ? v->s2[k] : 0.0; vel[2 * k + 1] = k < A ? v->s3[k] : 0.0;
             mov[k] = k < A; col[k] = (k < A) || (k >= A + v->L);     /* landmarks collide=False (…_july.py:298) */
             ms[k] = (k < A && c->max_speed > 0) ? c->max_speed : NAN;
         }
-        for (int i = 0; i < A; ++i) { double u[2]; decode_action(c, act[i], u); F[2 * i] = 1.0 * u[0]; F[2 * i + 1] = 1.0 * u[1]; }
-        gmpo_force_step(E, A, pos, vel, F, mov, col, NULL, c->sep_dist, v->status, NULL, ms, c->num_walls, c->walls,
-                        c->dt, c->damping, c->contact_force, c->contact_margin, c->wall_contact_force,
+        for (int i = 0; i < A; ++i) {
+            double u[2]; decode_action(c, act[i], u); filtered_control(h, n, i, u);
+            const double sc = classic ? c->action_force_scale : 1.0;       /* mpe/core.py:211-213: mass * accel (or mass) */
+            F[2 * i] = sc * u[0]; F[2 * i + 1] = sc * u[1];
+        }
+        gmpo_force_step(E, A, pos, vel, F, mov, col, classic ? size : NULL, c->sep_dist, classic ? NULL : v->status, classic ? mass : NULL, ms,
+                        c->num_walls, c->walls, c->dt, c->damping, c->contact_force, c->contact_margin, c->wall_contact_force,
                         c->wall_contact_margin, v->p_dist, v->time);
         for (int i = 0; i < A; ++i) { v->x[i] = pos[2 * i]; v->y[i] = pos[2 * i + 1]; v->s2[i] = vel[2 * i]; v->s3[i] = vel[2 * i + 1]; }
     }

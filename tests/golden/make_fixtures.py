@@ -4,6 +4,7 @@
 
 Vectors (data only — inputs and the reference's outputs):
   rotinv_A{3,6,10}_s{seed}.npz  the same for nav_graph_metered_single_corridor_rot_inv (float32 obs, 7 node features).
+  julyglobal_A{3,6}_s{seed}.npz  the July rollouts with graph_feat_type='global' (7 node features in world coordinates).
   july_A{3,10}_s{seed}.npz   end-to-end rollouts of MultiAgentGraphEnv (July tube scenario, air_taxi),
                              driven like graphworker does (env_wrappers.py:851-873: step, auto-reset
                              when all agents are done), with the uniform-sample tape that replays the
@@ -81,9 +82,10 @@ def _guided_action(w, sc, rng, w_opt, a_opt):
 
 
 def july_rollout(num_agents, seed, T, world_size=4.0, episode_length=25, guided=False,
-                 scenario_name="nav_metered_one_goal_graph_rotate_tube_july"):
+                 scenario_name="nav_metered_one_goal_graph_rotate_tube_july", graph_feat_type="relative"):
     np.random.seed(seed)
-    args = H.july_args(num_agents, world_size=world_size, episode_length=episode_length, scenario_name=scenario_name)
+    args = H.july_args(num_agents, world_size=world_size, episode_length=episode_length, scenario_name=scenario_name,
+                       graph_feat_type=graph_feat_type)
     info_keys = INFO_KEYS + (["Phase_reached"] if ("rot_inv" in scenario_name or "phase_graph" in scenario_name) else [])
     with H.UniformTape() as tape:
         env, sc, w = H.make_july_env(args)
@@ -358,6 +360,24 @@ def main_rot(ROT="nav_graph_metered_single_corridor_rot_inv", prefix="rotinv", s
               "max phase", int(d["obs"][:, :, phase_col].max()), "phase_reached", d["st_phase_reached"].max(axis=0), "cooldown max", d["st_cooldown"].max())
 
 
+def main_global():
+    # graph_feat_type='global' (_get_entity_feat_global, …_july.py:1672-1691): node rows [vel, pos, goal, type] in world coordinates, F = 7
+    seed = 5
+    for A, T, ws, el, guided in [(3, 60, 4.0, 25, False), (6, 120, 3.0, 60, True)]:
+        while True:                                   # the reference crashes at construction for some seeds (see main_rot)
+            seed += 1
+            try:
+                d = july_rollout(A, seed, T, world_size=ws, episode_length=el, guided=guided, graph_feat_type="global")
+                break
+            except AttributeError as e:
+                print("seed", seed, "reference crashed:", str(e)[:70])
+        d["graph_feat_type"] = "global"
+        p = os.path.join(HERE, "julyglobal_A%d_s%d%s.npz" % (A, seed, "_guided" if guided else ""))
+        np.savez_compressed(p, **d)
+        print(p, os.path.getsize(p), "node row width", d["node"].shape[-1], "resets", int(d["did_reset"].sum()),
+              "steps with a done agent", int(d["st_status"].any(axis=1).sum()), "phase_reached", d["st_phase_reached"].max(axis=0))
+
+
 def main_blocks():
     np.savez_compressed(os.path.join(HERE, "rk45_airtaxi.npz"), **rk45_fixture())
     np.savez_compressed(os.path.join(HERE, "force_classic.npz"), **force_classic_fixture())
@@ -368,9 +388,11 @@ def main_blocks():
 def main(which):
     """`python make_fixtures.py [july|rot|phase|blocks ...]` regenerates the named groups (default: all)."""
     H.selfcheck_uniform_patch()
-    which = which or ["july", "rot", "phase", "blocks"]
+    which = which or ["july", "global", "rot", "phase", "blocks"]
     if "july" in which:
         main_july()
+    if "global" in which:
+        main_global()
     if "rot" in which:
         main_rot()
     if "phase" in which:

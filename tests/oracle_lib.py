@@ -32,6 +32,7 @@ def load():
     lib.gmpo_get_field.argtypes = [P, C.c_int, P, C.c_size_t]
     lib.gmpo_set_field.argtypes = [P, C.c_int, P, C.c_size_t]
     lib.gmpo_set_rng_tape.argtypes = [P, P, C.c_int64]
+    lib.gmpo_set_control_override.argtypes = [P, P, P]
     lib.gmpo_get_dist_cache.argtypes = [P, P]
     lib.gmpo_reset.argtypes = [P, P, P, P, P, P]
     lib.gmpo_step.argtypes = [P, P, P, P, P, P, P, P, P, P, C.c_int]
@@ -91,6 +92,14 @@ class Oracle(object):
         t = np.ascontiguousarray(np.asarray(tape, dtype=np.float64).reshape(self.N, -1))
         self._tape = t
         self.lib.gmpo_set_rng_tape(self.h, _p(t), t.shape[1])
+
+    def set_control_override(self, ctrl=None, use=None):
+        """World.step's safety-filter slot: float64 [N,A,2] controls integrated where use [N,A] is non-zero (None: everywhere)."""
+        self._ovr = None if ctrl is None else (np.ascontiguousarray(ctrl, dtype=np.float64), None if use is None else np.ascontiguousarray(use, dtype=np.uint8))
+        if self._ovr is None:
+            self.lib.gmpo_set_control_override(self.h, None, None)
+        else:
+            self.lib.gmpo_set_control_override(self.h, _p(self._ovr[0]), _p(self._ovr[1]))
 
     def _bufs(self):
         N, A, E, D = self.N, self.A, self.E, self.D

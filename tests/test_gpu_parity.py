@@ -16,7 +16,7 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-JULY = [q for pre in ("july", "rotinv", "twophase", "threephase") for q in sorted(glob.glob(os.path.join(GOLD, pre + "_A*_s*.npz")))]
+JULY = [q for pre in ("july", "julyglobal", "rotinv", "twophase", "threephase") for q in sorted(glob.glob(os.path.join(GOLD, pre + "_A*_s*.npz")))]
 ROT = "nav_graph_metered_single_corridor_rot_inv"
 ROTFAM = [ROT, "two_phase_graph", "three_phase_graph"]
 TOL = 1e-5
@@ -44,7 +44,7 @@ def _july_cfg(d, scenario_name="nav_metered_one_goal_graph_rotate_tube_july", **
                             num_envs=1, num_agents=int(d["A"]), world_size=float(d["world_size"]),
                             episode_length=int(d["episode_length"]), max_speed=float(d["max_speed"]),
                             collision_rew=float(d["collision_rew"]), formation_rew=float(d["formation_rew"]),
-                            goal_rew=float(d["goal_rew"]), **kw)
+                            goal_rew=float(d["goal_rew"]), graph_feat_type=str(d["graph_feat_type"]) if "graph_feat_type" in d else "relative", **kw)
 
 
 @pytest.mark.parametrize("path", JULY, ids=[os.path.basename(p)[:-4] for p in JULY])
@@ -54,7 +54,7 @@ def test_golden_replay_on_gpu(path):
     A, E, T = int(d["A"]), int(d["E"]), int(d["T"])
     rot = not os.path.basename(path).startswith("july")              # the rot_inv family: float32 rotated features, F = 7
     eng = _engine(_july_cfg(d, str(d["scenario_name"])) if rot else _july_cfg(d))     # the July fixtures predate the name field
-    assert _np(eng.out.node_obs).shape[-1] == (7 if rot else 8)
+    assert _np(eng.out.node_obs).shape[-1] == (7 if (rot or "global" in os.path.basename(path)) else 8)
     eng.set("prev_phase", d["init_prev_phase"][None])
     eng.set_tape(d["tape"][None])
     o = eng.reset()

@@ -56,6 +56,8 @@ def test_config_pod_layout_matches_c_header():
              offsetof(gmpe_config, world_size), offsetof(gmpe_config, dt), offsetof(gmpe_config, ang_rate_opt),
              offsetof(gmpe_config, sensitivity), offsetof(gmpe_config, walls), sizeof(gmpe_outputs));
       printf("%d %d\n", (int)GMPE_F_ERROR_FLAGS, (int)GMPE_F_COUNT);
+      printf("%zu %zu %zu %zu %zu\n", offsetof(gmpe_config, graph_feat_type), offsetof(gmpe_config, agent_size), offsetof(gmpe_config, action_force_scale),
+             sizeof(gmpe_rollout), sizeof(gmpe_tuning));
       return 0; }'''
     with tempfile.TemporaryDirectory() as td:
         cpath = os.path.join(td, "t.c")
@@ -69,6 +71,9 @@ def test_config_pod_layout_matches_c_header():
                                          G.ang_rate_opt.offset, G.sensitivity.offset, G.walls.offset,
                                          C.sizeof(GmpeOutputs)]
     assert int(out[8]) == gcfg.FIELDS["error_flags"][0] and int(out[9]) == len(gcfg.FIELDS)
+    from gmpe._lib import GmpeRollout, GmpeTuning
+    assert [int(x) for x in out[10:15]] == [G.graph_feat_type.offset, G.agent_size.offset, G.action_force_scale.offset,
+                                            C.sizeof(GmpeRollout), C.sizeof(GmpeTuning)]
 
 
 def test_create_without_gpu_fails_loudly():
@@ -124,11 +129,16 @@ def test_config_from_args_mirrors_reference_fields():
     assert (c.num_envs, c.num_agents, c.num_entities, c.obs_dim, c.n_actions) == (128, 10, 20, 19, 25)
     assert c.dt == 1.0 and abs(c.sep_dist - 0.4572) < 1e-12 and c.goal_thresh == 0.35
     assert gcfg.algorithmic_bytes_per_env_step(c) == 24250
-    a.use_safety_filter = True
+    # graph_feat_type='global' (…_july.py:1672-1691) is a node-row variant: F = 7; use_safety_filter is a vec-env concern (hook slot)
+    a.graph_feat_type = "global"
+    cg = gmpe.config_from_args(a)
+    assert cg.graph_feat_type == 1 and cg.node_feats == 7 and gcfg.algorithmic_bytes_per_env_step(cg) == 24250 - 4 * 10 * 20
+    a.graph_feat_type = "relative"
+    a.scenario_name = "two_phase_graph"
+    a.graph_feat_type = "global"
     with pytest.raises(NotImplementedError):
         gmpe.config_from_args(a)
-    a.use_safety_filter = False
-    a.scenario_name = "two_phase_graph"
+    a.graph_feat_type = "relative"
     c3 = gmpe.config_from_args(a)
     assert (c3.obs_dim, c3.node_feats, c3.n_actions) == (15, 7, 25)
     a.scenario_name = "nav_metered_one_goal_graph_sequential_split_tube"      # a scenario file this engine does not build
@@ -137,6 +147,13 @@ def test_config_from_args_mirrors_reference_fields():
     c2 = gmpe.make_config(scenario_name="navigation_graph", num_agents=32, num_obstacles=8, num_walls=4, world_size=8.0)
     assert c2.num_entities == 72 and c2.obs_dim == 13 and c2.n_actions == 5 and c2.dt == 0.1
     assert [c2.walls[i].orient for i in range(4)] == [0, 0, 1, 1]
+    # force-path constant families: multiagent/core.py:542-548 vs classic onpolicy/envs/mpe/core.py:125-130
+    assert (c2.contact_family, c2.contact_force, c2.contact_margin, c2.wall_contact_force, c2.agent_mass, c2.action_force_scale) == (0, 300.0, 0.02, 220.0, 1.0, 1.0)
+    cc = gmpe.make_config(scenario_name="navigation_graph", num_agents=4, contact_family="classic", agent_size=0.15, collider_size=0.2, agent_accel=3.0)
+    assert (cc.contact_family, cc.contact_force, cc.contact_margin, cc.wall_contact_force, cc.wall_contact_margin) == (1, 100.0, 1e-3, 100.0, 1e-3)
+    assert (cc.agent_size, cc.collider_size, cc.agent_mass, cc.action_force_scale, cc.sensitivity) == (0.15, 0.2, 1.0, 3.0, 3.0)
+    with pytest.raises(NotImplementedError):
+        gmpe.make_config(contact_family="classic")              # kinematic scenario: no force path
 
 
 def test_spaces_are_duck_type_compatible():
