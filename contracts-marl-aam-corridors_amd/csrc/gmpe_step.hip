@@ -469,8 +469,14 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     {
         const double out_bytes = (double)N * h->A * ((double)E * E + 8.0 * E) * 4.0;
         h->nt = getenv("GMPE_NT") ? atoi(getenv("GMPE_NT")) : (out_bytes > 192.0 * 1024 * 1024 ? 1 : 0);
-        // The same launches split the adjacency fill from the fused kernel (see k_adj_expand): c4 1290 -> ~1030 us.
-        h->split = getenv("GMPE_SPLIT") ? atoi(getenv("GMPE_SPLIT")) : (out_bytes > 192.0 * 1024 * 1024 && h->A >= 48 ? 1 : 0);
+        // Split path (fused kernel -> compact matrix, k_adj_expand -> A copies, chunk-pipelined; see split_pipeline): measured to pay only
+        // in a narrow regime — adjacency >= ~95 % of the bytes (A >= 48) AND a launch of at most ~8 rounds of resident tiles: c5 per-GPU
+        // shard (2048 envs x 64 agents) 1522 us split vs 1731 fused, but 4096 envs 3658 vs 3373, 16384 envs 15.8 vs 13.0 ms; c4 (A = 32)
+        // 1252 vs 1177 (profiles/README.md). Everything else runs the fused kernel.
+        const size_t tiles_resident = (size_t)dev_cus * (size_t)[&] { const int q = sc_dispatch_occ(sc_of(h->c), block_sel ? block_sel : 256, ap_sel, lds_bytes(G, h->A, E, h->D, cfg->num_walls)); return q > 0 ? q : 1; }();
+        const size_t tiles_total = (N + G - 1) / G;
+        h->split = getenv("GMPE_SPLIT") ? atoi(getenv("GMPE_SPLIT"))
+                                        : (out_bytes > 192.0 * 1024 * 1024 && h->A >= 48 && tiles_total <= 8 * tiles_resident ? 1 : 0);
         if ((uint64_t)N * E * E >= (1ull << 32)) h->split = 0;            // k_adj_expand indexes the compact matrix with 32 bits
         h->roll = getenv("GMPE_ROLL") ? atoi(getenv("GMPE_ROLL")) : 1;
         if ((uint64_t)h->A * E * E / 4 * (E * E / 4 + 1) >= (1ull << 32)) h->split = 0;   // k_adj_expand's exact magic division
@@ -480,7 +486,11 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
             if (e != hipSuccess) { gmpe_destroy(h); return fail(GMPE_ERR_HIP, std::string("hipMalloc(adjacency scratch): ") + hipGetErrorString(e)); }
             h->allocs.push_back(q);
             h->adj_scratch = static_cast<float*>(q);
-            h->chunks = getenv("GMPE_CHUNKS") ? atoi(getenv("GMPE_CHUNKS")) : 8;
+            // one chunk = about one full round of resident tiles (c5 shard of 2048 envs: 8 chunks of 256 envs)
+            h->chunks = (int)((tiles_total + tiles_resident - 1) / tiles_resident);
+            if (h->chunks < 4) h->chunks = 4;
+            if (h->chunks > 128) h->chunks = 128;
+            if (getenv("GMPE_CHUNKS")) h->chunks = atoi(getenv("GMPE_CHUNKS"));
             if (h->chunks < 1) h->chunks = 1;
             if ((size_t)h->chunks > N) h->chunks = (int)N;
             bool ok = true;
@@ -694,6 +704,7 @@ int gmpe_rollout_steps(gmpe_handle* h, const int32_t* actions_dev, const gmpe_ro
     if (r->num_steps < 1 || r->num_action_sets < 1 || r->num_slots < 1 || r->first_slot < 0 || r->first_slot >= r->num_slots)
         return fail(GMPE_ERR_INVALID_ARG, "gmpe_rollout_steps: bad step / slot counts");
     if (h->split) return fail(GMPE_ERR_UNSUPPORTED, "gmpe_rollout_steps: this handle runs the split big-E path (use gmpe_step_many)");
+
     KParams p;
     fill_params(h, p, h->G_roll);
     if (slot0) p.o = *slot0;

@@ -108,7 +108,7 @@ class DeviceRolloutBuffer(object):
         insert_step calls. Falls back to that loop on the split big-E path."""
         K = self.T - self.step if num_steps is None else int(num_steps)
         e = self.engine
-        if e.tuning()["split"]:
+        if e.tuning()["split"] or not e.tuning()["roll"]:
             for k in range(K):
                 self.insert_step(action_sets[k % action_sets.shape[0]])
             return e.out
