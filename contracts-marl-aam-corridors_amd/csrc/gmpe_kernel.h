@@ -658,7 +658,7 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
 // FL = 1: the steady-state instantiation — step mode, wave specialisation on, ordinary stores, no ablation — with those run-time
 // flags folded (selected by the host when they hold; everything else takes FL = 0).
 template <int BLOCK, int AP, int SC, int FL>
-__global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL == 2 && BLOCK > 64 ? (SC == SC_ROT ? 3 : 4) : (AP > 0 && BLOCK > 64 ? (sc_rotfam(SC) ? 3 : 4) : GMPE_MIN_WAVES_NOWALLS)))) void k_env(const KParams p_arg) {
+__global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL == 2 && BLOCK > 64 ? ((SC == SC_ROT || (AP > 0 && sc_kinematic(SC))) ? 3 : 4) : (AP > 0 && BLOCK > 64 ? (sc_rotfam(SC) ? 3 : 4) : GMPE_MIN_WAVES_NOWALLS)))) void k_env(const KParams p_arg) {
     const KParams& p = p_arg;
     constexpr bool WALLS = SC == SC_NAV_WALLS;
     extern __shared__ __attribute__((aligned(16))) char smem[];

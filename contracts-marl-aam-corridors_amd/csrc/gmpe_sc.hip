@@ -1,7 +1,7 @@
 // gmpe_sc.hip — one scenario variant of the fused kernel per translation unit (compiled with -DGMPE_SC=<variant>, in
 // parallel): tile shapes BLOCK in {64,128,256} x exact-size instantiations AP in {0,3,10}, plus the steady-state instantiation
 // <256, 10, SC, FL = 1> (run-time flags folded) that the C2/C3-shaped workloads run, plus the rollout instantiations
-// <{64, 256}, 0, SC, FL = 2> (K steps inside one launch, gmpe_rollout_steps).
+// <64, 0, SC, 2>, <256, {0, 10}, SC, 2> (FL = 2: K steps inside one launch, gmpe_rollout_steps).
 #include "gmpe_kernel.h"
 
 #ifndef GMPE_SC
@@ -12,8 +12,13 @@ namespace gmpe {
 
 template <int SC>
 void launch_env(int block, int ap, int fl, dim3 grid, size_t lds, hipStream_t st, const KParams& p) {
-    if (fl == 2) {                                                       // persistent rollout kernel: BLOCK 64 or 256, run-time sizes (<= 128 VGPRs = four
-        if (block == 64) hipLaunchKernelGGL((k_env<64, 0, SC, 2>), grid, dim3(64), lds, st, p);      // tiles per CU; the exact-size variants would spill there)
+    if (fl == 2) {
+        // persistent rollout kernel: BLOCK 64 (run-time sizes) or 256 (run-time sizes, or exact-size for A = L = 10). Register budgets
+        // (__launch_bounds__ in gmpe_kernel.h), measured per scenario on one box (profiles/README.md): navigation_graph exact-size at four
+        // tiles per CU (G = 4; spills 5 dwords, 17.0 us per step vs 18.3 at three tiles / G = 6 without a spill, 19.9 run-time sizes); the
+        // kinematic scenarios exact-size at three tiles per CU (G = 6, no spill: July 15.8 us vs 18.0 at four tiles with a 14-dword spill).
+        if (block == 64) hipLaunchKernelGGL((k_env<64, 0, SC, 2>), grid, dim3(64), lds, st, p);
+        else if (ap == 10) hipLaunchKernelGGL((k_env<256, 10, SC, 2>), grid, dim3(256), lds, st, p);
         else hipLaunchKernelGGL((k_env<256, 0, SC, 2>), grid, dim3(256), lds, st, p);
         return;
     }
@@ -35,12 +40,13 @@ void launch_env(int block, int ap, int fl, dim3 grid, size_t lds, hipStream_t st
 template <int SC>
 hipError_t set_max_lds(int lds) {
 #define FN(B, P) reinterpret_cast<const void*>(&k_env<B, P, SC, 0>)
-    const void* fns[12] = {FN(64, 0), FN(64, 3), FN(64, 10), FN(128, 0), FN(128, 3), FN(128, 10), FN(256, 0), FN(256, 3), FN(256, 10),
+    const void* fns[13] = {FN(64, 0), FN(64, 3), FN(64, 10), FN(128, 0), FN(128, 3), FN(128, 10), FN(256, 0), FN(256, 3), FN(256, 10),
                            reinterpret_cast<const void*>(&k_env<256, 10, SC, 1>),
-                           reinterpret_cast<const void*>(&k_env<64, 0, SC, 2>), reinterpret_cast<const void*>(&k_env<256, 0, SC, 2>)};
+                           reinterpret_cast<const void*>(&k_env<64, 0, SC, 2>), reinterpret_cast<const void*>(&k_env<256, 0, SC, 2>),
+                           reinterpret_cast<const void*>(&k_env<256, 10, SC, 2>)};
 #undef FN
     hipError_t e = hipSuccess;
-    for (int q = 0; q < 12 && e == hipSuccess; ++q) e = hipFuncSetAttribute(fns[q], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    for (int q = 0; q < 13 && e == hipSuccess; ++q) e = hipFuncSetAttribute(fns[q], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     return e;
 }
 
@@ -50,7 +56,8 @@ int max_tiles_per_cu(int block, int ap, size_t lds, int roll) {
 #define FN(B, P) reinterpret_cast<const void*>(&k_env<B, P, SC, 0>)
 #define PICK(B) (ap == 10 ? FN(B, 10) : (ap == 3 ? FN(B, 3) : FN(B, 0)))
     if (roll) block = block == 64 ? 64 : 256;
-    const void* fn = roll ? (block == 64 ? reinterpret_cast<const void*>(&k_env<64, 0, SC, 2>) : reinterpret_cast<const void*>(&k_env<256, 0, SC, 2>))
+    const void* fn = roll ? (block == 64 ? reinterpret_cast<const void*>(&k_env<64, 0, SC, 2>)
+                                         : (ap == 10 ? reinterpret_cast<const void*>(&k_env<256, 10, SC, 2>) : reinterpret_cast<const void*>(&k_env<256, 0, SC, 2>)))
                           : block == 64 ? PICK(64) : (block == 128 ? PICK(128) : (ap == 10 ? reinterpret_cast<const void*>(&k_env<256, 10, SC, 1>) : PICK(256)));
 #undef PICK
 #undef FN

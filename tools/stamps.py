@@ -18,8 +18,12 @@ print("tuning", eng.tuning())
 eng.reset()
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 acts = torch.randint(0, cfg.n_actions, (40, N, cfg.num_agents), generator=g, device="cuda", dtype=torch.int32)
-for k in range(20):
-    eng.step(acts[k])
+ROLLOUT = len(sys.argv) > 3 and sys.argv[3] == "roll"      # stamps of the LAST step of a K-step rollout launch (k_env<*, 0, SC, 2>)
+if ROLLOUT:
+    eng.rollout(acts, 37)
+else:
+    for k in range(20):
+        eng.step(acts[k])
 torch.cuda.synchronize()
 lib = _lib.load()
 lib.gmpe_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
