@@ -475,7 +475,7 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
     constexpr bool CT = AP > 0 && SC != SC_NAV_WALLS;
     const int A = CT ? AP : p.A, L = CT ? AP : p.L, E = CT ? 2 * AP : p.E, EE = E * E, EE4 = (EE + 3) / 4 * 4;
     const int abl = FL ? 0 : GMPE_ABL(p);
-    const bool nt = FL ? false : p.nt != 0;                              // FL: the steady-state instantiation (step, no ablation, ordinary stores)
+    const bool nt = FL == 1 ? false : p.nt != 0;                         // FL = 1: the steady-state instantiation (step, no ablation, ordinary stores); rollouts: by slot volume
     // ---- 6. adjacency mask (…_july.py:1627-1648): rows/cols of done agents and reached landmarks -> 0.
     // Only tiles that contain such an entity pay for this pass.
     if (do_mask && any_mask && !(abl & 4)) {

@@ -713,6 +713,10 @@ int gmpe_rollout_steps(gmpe_handle* h, const int32_t* actions_dev, const gmpe_ro
     p.st_obs = r->stride_obs; p.st_id = r->stride_agent_id; p.st_node = r->stride_node_obs; p.st_adj = r->stride_adj;
     p.st_rew = r->stride_reward; p.st_done = r->stride_done; p.st_info = r->stride_info; p.st_mask = r->stride_masks;
     p.masks = r->masks; p.active = r->active_masks;
+    {   // a rollout that fills more slots than the 256 MiB Infinity Cache holds streams past it: nontemporal graph stores (like the big launches)
+        const double step_bytes = (double)h->c.num_envs * h->A * ((double)h->E * h->E * (p.o.adj_compact ? 1.0 / h->A : 1.0) + (double)h->F * h->E) * 4.0;
+        p.nt = getenv("GMPE_ROLLNT") ? atoi(getenv("GMPE_ROLLNT")) : (step_bytes * r->num_slots > 192.0 * 1024 * 1024 ? 1 : 0);
+    }
     HIPCHK(hipSetDevice(h->device));
     dispatch_env(h, h->block_roll, ap_of(h), 2, static_cast<hipStream_t>(stream), p);
     HIPCHK(hipGetLastError());

@@ -211,3 +211,24 @@ def test_full_size_rollout_c2_properties_and_slice():
     adj = o.adj
     assert torch.equal(adj, adj.transpose(-1, -2)) and torch.equal(adj, adj[:, :1].expand_as(adj))
     eng.check_errors()
+
+
+def test_rollout_nontemporal_store_variant_equals_step_loop(monkeypatch):
+    """Rollouts that fill more slots than the Infinity Cache holds use nontemporal graph stores (GMPE_ROLLNT forces it at small size)."""
+    import torch
+    monkeypatch.setenv("GMPE_ROLLNT", "1")
+    for scen, F in ((JULY, 8), (ROTFAM[0], 7), ("navigation_graph", 8)):
+        cfg = gmpe.make_config(scenario_name=scen, num_envs=45, num_agents=10, world_size=4.0, episode_length=6, seed=55)
+        e1, e2 = _engine(cfg), _engine(cfg)
+        e1.reset(); e2.reset()
+        g = torch.Generator(device="cuda"); g.manual_seed(4)
+        acts = torch.randint(0, cfg.n_actions, (3, 45, 10), generator=g, device="cuda", dtype=torch.int32)
+        ref = []
+        for k in range(13):
+            o = e1.step(acts[k % 3])
+            ref.append({key: getattr(o, key).clone() for key in OUT_KEYS})
+        st = _rollout_into_slots(e2, acts, 13, 13)
+        for k in range(13):
+            for key in OUT_KEYS:
+                assert torch.equal(st[key][k], ref[k][key]), (scen, key, k)
+        _compare_state(e1, e2, scen)
