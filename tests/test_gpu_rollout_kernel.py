@@ -186,11 +186,12 @@ def test_device_rollout_buffer_collect_equals_insert_loop(compact):
         assert torch.equal(getattr(b1, name), getattr(b2, name)), name
 
 
-def test_full_size_rollout_c2_properties_and_slice():
-    """The launch bench.py times by default (c2: 4096 x 10 navigation_graph, K steps in one launch): a 512-env oracle slice of the
-    final step + the graph invariants."""
+@pytest.mark.parametrize("scen", ["navigation_graph", JULY] + ROTFAM)
+def test_full_size_rollout_properties_and_slice(scen):
+    """The launches bench.py times (c2 by default, c3 / c3r / c3p2 / c3p3 with --workload: 4096 x 10, K steps in ONE launch of the exact-size
+    rollout kernel at its own tile shape): a 512-env oracle slice of the final step + the graph invariants."""
     import torch
-    kw = dict(scenario_name="navigation_graph", num_agents=10, world_size=4.0, episode_length=25, seed=1234)
+    kw = dict(scenario_name=scen, num_agents=10, world_size=4.0, episode_length=25, seed=1234)
     cfg = gmpe.make_config(num_envs=4096, **kw)
     eng, orc = _engine(cfg), ol.Oracle(gmpe.make_config(num_envs=512, **kw))
     eng.reset(); orc.reset()
@@ -203,6 +204,7 @@ def test_full_size_rollout_c2_properties_and_slice():
         oo = orc.step(a[k])
     np.testing.assert_allclose(_np(o.obs[:512]), oo[0], rtol=0, atol=TOL)
     np.testing.assert_allclose(_np(o.node_obs[:512]), oo[2], rtol=0, atol=TOL)
+    assert eng.tuning()["ap"] == 10 and eng.tuning()["G_roll"] == (4 if scen == "navigation_graph" else 6)
     np.testing.assert_allclose(_np(o.adj[:512]), np.broadcast_to(oo[3][:, None], (512, 10, 20, 20)), rtol=0, atol=TOL)
     np.testing.assert_allclose(_np(o.reward[:512]), oo[4], rtol=0, atol=TOL)
     np.testing.assert_array_equal(_np(o.done[:512]).astype(bool), oo[5])
