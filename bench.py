@@ -191,7 +191,7 @@ def main():
         eng.step(actions[k % n_act_sets])
 
     # ---- what one repetition of the timed region launches
-    rollout_ok = bool(tuning["roll"]) and not tuning["split"] and not tuning["nt"]
+    rollout_ok = bool(tuning["roll"]) and not tuning["split"]
     mode = "host-loop" if args.host_loop else ("launch-loop" if (args.launch_loop or not rollout_ok) else "rollout")
     slots = None
     if mode == "rollout" and args.slots > 1:

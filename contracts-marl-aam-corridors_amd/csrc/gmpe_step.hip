@@ -784,7 +784,7 @@ int gmpe_step_many(gmpe_handle* h, const int32_t* actions_dev, int32_t num_steps
                    const gmpe_outputs* out, void* stream) {
     if (!h || !actions_dev || num_steps < 0 || num_action_sets < 1) return fail(GMPE_ERR_INVALID_ARG, "gmpe_step_many: bad arguments");
     if (num_steps == 0) return GMPE_OK;
-    if (h->roll && !h->split && !h->timing && !h->nt && !h->ablate) {        // one launch: the persistent rollout kernel (same results as the launch loop)
+    if (h->roll && !h->split && !h->timing && !h->ablate) {                  // one launch: the persistent rollout kernel (same results as the launch loop)
         gmpe_rollout r; memset(&r, 0, sizeof r);
         r.num_steps = num_steps; r.num_action_sets = num_action_sets; r.num_slots = 1;
         return gmpe_rollout_steps(h, actions_dev, &r, out, stream);

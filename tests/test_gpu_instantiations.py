@@ -185,3 +185,33 @@ def test_split_pipeline_across_steps_equals_step_loop(monkeypatch, chunks):
             assert torch.equal(getattr(o1, key), getattr(o2, key)), (K, key)
         _compare_state(e1, e2, "K=%d" % K)
     e1.check_errors(); e2.check_errors()
+
+
+def test_full_size_c4_rollout_kernel_with_oracle_slice():
+    """configs[3] as bench.py --workload c4 times it since round 2: the K steps in ONE launch of the run-time-size rollout kernel with
+    nontemporal stores (k_env<256, 0, SC_NAV_WALLS, 2>, three tiles per CU, 8192 tiles queued behind 768 slots)."""
+    import torch
+    kw = dict(scenario_name="navigation_graph", num_agents=32, num_obstacles=8, num_walls=4, world_size=8.0, episode_length=6, seed=1234)
+    cfg = gmpe.make_config(num_envs=8192, **kw)
+    eng, orc = _engine(cfg), ol.Oracle(gmpe.make_config(num_envs=192, **kw))
+    t = eng.tuning()
+    assert t["roll"] == 1 and t["split"] == 0 and t["nt"] == 1
+    eng.reset(); orc.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(45)
+    K = 9
+    acts = torch.randint(0, cfg.n_actions, (K, 8192, 32), generator=g, device="cuda", dtype=torch.int32)
+    o = eng.step_many(acts, K)
+    a = acts[:, :192].cpu().numpy()
+    for k in range(K):
+        oo = orc.step(a[k])
+    np.testing.assert_allclose(_np(o.obs[:192]), oo[0], rtol=0, atol=TOL)
+    np.testing.assert_allclose(_np(o.node_obs[:192]), oo[2], rtol=0, atol=TOL)
+    adj = _np(o.adj[:192])
+    np.testing.assert_allclose(adj, np.broadcast_to(oo[3][:, None], adj.shape), rtol=0, atol=TOL)
+    np.testing.assert_allclose(_np(o.reward[:192]), oo[4], rtol=0, atol=TOL)
+    np.testing.assert_array_equal(_np(o.done[:192]).astype(bool), oo[5])
+    np.testing.assert_allclose(_np(o.info[:192]), oo[6], rtol=2e-6, atol=2e-5)
+    for f in ("rng_ctr", "current_step", "status", "n_obst_coll"):
+        np.testing.assert_array_equal(eng.get(f)[:192], orc.get(f), err_msg=f)
+    _graph_invariants(o, 32, 72, 8)
+    eng.check_errors()
