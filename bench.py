@@ -87,7 +87,7 @@ def cpu_baseline(wl, budget_s=12.0):
                       "(oracle/gmpe_oracle.c, fp64 outputs)" % (n, steps, el)}
 
 
-def numpy_boundary(wl, n_envs, device, steps=12):
+def numpy_boundary(wl, n_envs, device, steps=30):
     """PCIe-inclusive rate of the drop-in boundary the unchanged runner uses (never `value`): BatchedGraphMPEVecEnv.step with the
     runner's float one-hot actions [N,A,n_act] in NumPy and NumPy observations out (graph_mpe_runner.py:343-382)."""
     import argparse as ap
@@ -102,17 +102,23 @@ def numpy_boundary(wl, n_envs, device, steps=12):
     env.reset()
     rng = np.random.RandomState(0)
     n_act = env.action_space[0].n
-    onehot = np.eye(n_act, dtype=np.float32)[rng.randint(0, n_act, (4, n_envs, wl["num_agents"]))]
+    onehot = np.eye(n_act)[rng.randint(0, n_act, (4, n_envs, wl["num_agents"]))]      # float64, exactly what the runner builds (graph_mpe_runner.py:375-377)
     for k in range(3):
         env.step(onehot[k % 4])
-    t0 = time.perf_counter()
+    per = []
     for k in range(steps):
+        t0 = time.perf_counter()
         env.step(onehot[k % 4])
-    el = time.perf_counter() - t0
+        per.append(time.perf_counter() - t0)
     env.close()
-    return {"value": n_envs * steps / el, "unit": "env-steps/s", "ms_per_step": el / steps * 1e3, "steps": steps,
-            "what": "BatchedGraphMPEVecEnv.step: float32 one-hot NumPy actions in (pinned H2D), NumPy obs / node_obs / adj (zero-copy "
-                    "broadcast of the compact matrix) / reward / done out (pinned D2H); PCIe-inclusive, never `value`"}
+    per.sort()
+    med = per[len(per) // 2]
+    # the MEDIAN step is reported: on the gpurun boxes about one HIP call in 30 steps blocks for ~90 ms whatever the call (profiles/r02_notes.md),
+    # which a mean over 30 steps would turn into +3 ms per step
+    return {"value": n_envs / med, "unit": "env-steps/s", "ms_per_step": med * 1e3, "mean_ms_per_step": sum(per) / len(per) * 1e3, "max_ms": per[-1] * 1e3,
+            "steps": steps,
+            "what": "median BatchedGraphMPEVecEnv.step: float64 one-hot NumPy actions in (converted into pinned staging, H2D), NumPy obs / node_obs / "
+                    "adj (zero-copy broadcast of the compact matrix) / reward / done out (pinned D2H); PCIe-inclusive, never `value`"}
 
 
 def main():

@@ -107,6 +107,14 @@ class BatchedGraphMPEVecEnv(object):
             mk = lambda t: torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
             self._host = [dict(obs=mk(o.obs), agent_id=mk(o.agent_id), node_obs=mk(o.node_obs), adj=mk(o.adj),
                                reward=mk(o.reward), done=mk(o.done)) for _ in range(2)]
+        # Actions go up through pinned staging too: whatever dtype the runner hands over (np.eye(n)[a] is float64, indices are int64) is
+        # converted straight INTO the pinned buffer and uploaded from there. A dtype-converted temporary in pageable memory made the
+        # whole step 6.6 ms instead of 0.87 (tools/hostpath2.py): the asynchronous copy from a fresh pageable allocation is a slow path.
+        dev = self.engine.device
+        self._act_host = dict(onehot=torch.empty((c.num_envs, A, c.n_actions), dtype=torch.float32, pin_memory=self._pinned),
+                              index=torch.empty((c.num_envs, A), dtype=torch.int32, pin_memory=self._pinned))
+        self._act_dev = dict(onehot=torch.empty((c.num_envs, A, c.n_actions), dtype=torch.float32, device=dev),
+                             index=torch.empty((c.num_envs, A), dtype=torch.int32, device=dev))
 
     # ------------------------------------------------------------------ helpers
     def _expand_adj(self, a):
@@ -145,20 +153,29 @@ class BatchedGraphMPEVecEnv(object):
         else:
             a = np.asarray(actions)
         if a.ndim == 3:
-            if a.shape != (self.num_envs, self.num_agents, self.cfg.n_actions):
+            if tuple(a.shape) != (self.num_envs, self.num_agents, self.cfg.n_actions):
                 raise ValueError("actions must be [N=%d, A=%d, %d]" % (self.num_envs, self.num_agents, self.cfg.n_actions))
-            t = torch.as_tensor(a, dtype=torch.float32).to(self.engine.device, non_blocking=True)
+            t = self._upload(a, "onehot")
             self._filter(t)
             self._pending = self.engine.step_onehot(t)
         elif a.ndim == 2:
             if tuple(a.shape) != (self.num_envs, self.num_agents):
                 raise ValueError("actions must be [N=%d, A=%d]" % (self.num_envs, self.num_agents))
-            t = torch.as_tensor(a).to(dtype=torch.int32).to(self.engine.device, non_blocking=True)
+            t = self._upload(a, "index")
             self._filter(t)
             self._pending = self.engine.step(t)
         else:
             raise ValueError("actions must be a one-hot [N,A,n_act] or an index [N,A] array")
         self.waiting = True
+
+    def _upload(self, a, kind):
+        """Host (NumPy / CPU tensor, any numeric dtype) or device actions -> the engine's device tensor of the right dtype."""
+        dst = self._act_dev[kind]
+        if torch.is_tensor(a) and a.is_cuda:
+            return a if (a.dtype == dst.dtype and a.is_contiguous() and a.device == dst.device) else dst.copy_(a)
+        stage = self._act_host[kind]
+        stage.copy_(torch.as_tensor(a))                  # dtype conversion happens here, into pinned memory
+        return dst.copy_(stage, non_blocking=True)
 
     def _filter(self, actions_dev):
         if self._safety_filter is not None:
