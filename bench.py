@@ -113,8 +113,8 @@ def numpy_boundary(wl, n_envs, device, steps=30):
     env.close()
     per.sort()
     med = per[len(per) // 2]
-    # the MEDIAN step is reported: on the gpurun boxes about one HIP call in 30 steps blocks for ~90 ms whatever the call (profiles/r02_notes.md),
-    # which a mean over 30 steps would turn into +3 ms per step
+    # median AND mean are reported: they agree since the action conversion is single-threaded NumPy (a 128-thread torch CPU op per step got the
+    # process CPU-throttled for ~90 ms about once in 30 steps under the boxes' 16-CPU quota: profiles/r02_notes.md)
     return {"value": n_envs / med, "unit": "env-steps/s", "ms_per_step": med * 1e3, "mean_ms_per_step": sum(per) / len(per) * 1e3, "max_ms": per[-1] * 1e3,
             "steps": steps,
             "what": "median BatchedGraphMPEVecEnv.step: float64 one-hot NumPy actions in (converted into pinned staging, H2D), NumPy obs / node_obs / "

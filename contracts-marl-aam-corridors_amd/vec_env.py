@@ -108,8 +108,7 @@ class BatchedGraphMPEVecEnv(object):
             self._host = [dict(obs=mk(o.obs), agent_id=mk(o.agent_id), node_obs=mk(o.node_obs), adj=mk(o.adj),
                                reward=mk(o.reward), done=mk(o.done)) for _ in range(2)]
         # Actions go up through pinned staging too: whatever dtype the runner hands over (np.eye(n)[a] is float64, indices are int64) is
-        # converted straight INTO the pinned buffer and uploaded from there. A dtype-converted temporary in pageable memory made the
-        # whole step 6.6 ms instead of 0.87 (tools/hostpath2.py): the asynchronous copy from a fresh pageable allocation is a slow path.
+        # converted straight INTO the pinned buffer (single-threaded NumPy, see _upload) and uploaded from there.
         dev = self.engine.device
         self._act_host = dict(onehot=torch.empty((c.num_envs, A, c.n_actions), dtype=torch.float32, pin_memory=self._pinned),
                               index=torch.empty((c.num_envs, A), dtype=torch.int32, pin_memory=self._pinned))
@@ -174,7 +173,10 @@ class BatchedGraphMPEVecEnv(object):
         if torch.is_tensor(a) and a.is_cuda:
             return a if (a.dtype == dst.dtype and a.is_contiguous() and a.device == dst.device) else dst.copy_(a)
         stage = self._act_host[kind]
-        stage.copy_(torch.as_tensor(a))                  # dtype conversion happens here, into pinned memory
+        # dtype conversion straight into pinned memory — with NumPy on purpose: a torch CPU op of this size fans out over every host
+        # core (128 OpenMP threads on the MI355X boxes), and under a CPU quota their spin-waiting gets the whole process throttled for the
+        # rest of the scheduler period (~90 ms stalls once per ~30 steps, tools/hostpath3.py)
+        np.copyto(stage.numpy(), a.numpy() if torch.is_tensor(a) else a, casting="unsafe")
         return dst.copy_(stage, non_blocking=True)
 
     def _filter(self, actions_dev):

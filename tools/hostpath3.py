@@ -20,11 +20,22 @@ for name, oh in (("f32 onehot", np.eye(25, dtype=np.float32)[idx]), ("f64 onehot
         x = oh[k % 4]
         t0 = P(); t = env._upload(np.asarray(x), "onehot" if x.ndim == 3 else "index"); t1 = P()
         o = env.engine.step_onehot(t) if x.ndim == 3 else env.engine.step(t); t2 = P()
-        torch.cuda.current_stream().synchronize(); t3 = P()
+        if os.environ.get("SPIN"):
+            ev0 = torch.cuda.Event(); ev0.record()
+            while not ev0.query(): pass
+        else:
+            torch.cuda.current_stream().synchronize()
+        t3 = P()
         h = env._host[0]
         for key in ("obs", "agent_id", "node_obs", "adj", "reward", "done"):
             h[key].copy_(getattr(o, key), non_blocking=True)
-        t4 = P(); torch.cuda.current_stream().synchronize(); t5 = P()
+        t4 = P()
+        if os.environ.get("SPIN"):
+            ev = torch.cuda.Event(); ev.record()
+            while not ev.query(): pass
+        else:
+            torch.cuda.current_stream().synchronize()
+        t5 = P()
         done = h["done"].numpy().astype(bool); t6 = P()
         inf = LazyInfos(o.info.clone(), 4096, 10); t7 = P()
         rows.append([t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5, t7 - t6])
