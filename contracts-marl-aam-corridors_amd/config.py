@@ -181,8 +181,6 @@ def make_config(scenario_name="nav_metered_one_goal_graph_rotate_tube_july", dyn
     c.wall_contact_force, c.wall_contact_margin = 2.2e2, 2.4e-2        # core.py:545, 548
     if graph_feat_type not in ("relative", "global"):
         raise NotImplementedError("graph_feat_type %r" % (graph_feat_type,))
-    if graph_feat_type == "global" and scen in ROT_FAMILY:
-        raise NotImplementedError("graph_feat_type='global' is built for the July scenario and navigation_graph only")
     c.graph_feat_type = 1 if graph_feat_type == "global" else 0
     if contact_family not in ("multiagent", "classic"):
         raise NotImplementedError("contact_family %r" % (contact_family,))

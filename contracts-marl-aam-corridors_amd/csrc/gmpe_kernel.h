@@ -537,7 +537,7 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
         }
     }
     
-    if (sc_rotfam(SC) && o.node_obs && !(abl & 2)) {
+    if (sc_rotfam(SC) && o.node_obs && !(abl & 2) && p.c.graph_feat_type != 1) {
         // rot_inv node row (…rot_inv.py:1690-1766): 7 float32 = [rel_vel, rel_pos, rel_goal (all rotated by the ego heading), type].
         // Positions / velocities are rounded to float32 FIRST, differenced in float32, rotated in float64, rounded again.
         // A lane owns one (env, entity) and walks the egos; rows are 28 B, so the stores are scalar.
@@ -574,8 +574,8 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
             }
         }
     }
-    if (!sc_rotfam(SC) && o.node_obs && !(abl & 2) && p.c.graph_feat_type == 1) {
-        // graph_feat_type 'global' (_get_entity_feat_global, …_july.py:1672-1691): row (ego, entity k) = 7 floats [vel, pos, goal, type] in
+    if (o.node_obs && !(abl & 2) && p.c.graph_feat_type == 1) {
+        // graph_feat_type 'global' (_get_entity_feat_global, …_july.py:1672-1691; the same function in the rot_inv family's files): row (ego, entity k) = 7 floats [vel, pos, goal, type] in
         // world coordinates — the same for every ego except that ego i sees agent k's re-drawn velocity iff k reached its goal in this
         // step and k <= i (ordered-visibility rule). A lane owns one (env, entity) and walks the egos; 28-byte rows: scalar stores.
         float* base = o.node_obs + (size_t)n0 * A * E * 7;
@@ -658,7 +658,7 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
 // FL = 1: the steady-state instantiation — step mode, wave specialisation on, ordinary stores, no ablation — with those run-time
 // flags folded (selected by the host when they hold; everything else takes FL = 0).
 template <int BLOCK, int AP, int SC, int FL>
-__global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL == 2 && BLOCK > 64 ? ((SC == SC_ROT || (AP > 0 && sc_kinematic(SC))) ? 3 : 4) : (AP > 0 && BLOCK > 64 ? (sc_rotfam(SC) ? 3 : 4) : GMPE_MIN_WAVES_NOWALLS)))) void k_env(const KParams p_arg) {
+__global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL == 2 && BLOCK > 64 ? ((sc_rotfam(SC) || (AP > 0 && sc_kinematic(SC))) ? 3 : 4) : (AP > 0 && BLOCK > 64 ? (sc_rotfam(SC) ? 3 : 4) : GMPE_MIN_WAVES_NOWALLS)))) void k_env(const KParams p_arg) {
     const KParams& p = p_arg;
     constexpr bool WALLS = SC == SC_NAV_WALLS;
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -355,8 +355,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
         return fail(GMPE_ERR_UNSUPPORTED, "unknown scenario");
     if ((cfg->scenario != GMPE_SCENARIO_NAVIGATION_GRAPH) == (cfg->dynamics == GMPE_DYN_DOUBLE_INTEGRATOR))
         return fail(GMPE_ERR_UNSUPPORTED, "the tube scenarios are kinematic; navigation_graph is double_integrator");
-    if (cfg->graph_feat_type < 0 || cfg->graph_feat_type > 1 || (cfg->graph_feat_type == 1 && cfg->scenario >= GMPE_SCENARIO_ROT_INV))
-        return fail(GMPE_ERR_UNSUPPORTED, "graph_feat_type: 0 (relative) everywhere, 1 (global) for tube_july / navigation_graph");
+    if (cfg->graph_feat_type < 0 || cfg->graph_feat_type > 1) return fail(GMPE_ERR_UNSUPPORTED, "graph_feat_type: 0 (relative) or 1 (global)");
     if (cfg->contact_family < 0 || cfg->contact_family > 1 || (cfg->contact_family == 1 && (cfg->scenario != GMPE_SCENARIO_NAVIGATION_GRAPH || !(cfg->agent_mass > 0))))
         return fail(GMPE_ERR_UNSUPPORTED, "contact_family 1 (classic MPE) applies to navigation_graph and needs agent_mass > 0");
     if (cfg->dynamics == GMPE_DYN_DOUBLE_INTEGRATOR ? (cfg->n_actions != 5 && cfg->n_actions != 9) : cfg->n_actions != 25)

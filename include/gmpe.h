@@ -110,8 +110,8 @@ typedef struct gmpe_config {
     double damping, contact_force, contact_margin, wall_contact_force, wall_contact_margin;
     gmpe_wall walls[GMPE_MAX_WALLS];
     /* ---- ABI 2 ---- */
-    int32_t graph_feat_type;            /* 0 'relative' (…_july.py:1694-1771, F = 8); 1 'global' (…_july.py:1672-1691: [vel, pos,
-                                           goal, type] in world coordinates, F = 7; July and navigation_graph only)              */
+    int32_t graph_feat_type;            /* 0 'relative' (…_july.py:1694-1771, F = 8; rot_inv family F = 7); 1 'global' (…_july.py:1672-1691,
+                                           rot_inv.py:1668-1687: [vel, pos, goal, type] in world coordinates, F = 7, every scenario)  */
     int32_t contact_family;             /* force path constants: 0 = multiagent/core.py:872-906 (d_min = COLLISION_DISTANCE, no force on a
                                            done side, separate wall constants); 1 = classic MPE, onpolicy/envs/mpe/core.py:273-286
                                            (d_min = size_a + size_b, every collider side gets its force, walls share the contact

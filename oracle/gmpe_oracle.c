@@ -721,8 +721,8 @@ static double reward_nav(envv* v, int i) {
  * node: [E,8] for ego i. The adjacency is world.cached_dist_mag itself, masked IN PLACE. */
 static void graph_observation(envv* v, int i, double* node) {
     const int A = v->A, L = v->L, E = v->E;
-    if (is_rotfam(&v->h->c)) { node_features_rot(v, i, node); goto mask; }
-    if (v->h->c.graph_feat_type == 1) {                  /* _get_entity_feat_global, …_july.py:1672-1691: [vel, pos, goal, type] in world coordinates */
+    if (v->h->c.graph_feat_type == 1) {                  /* _get_entity_feat_global, …_july.py:1672-1691 (same code in rot_inv.py:1668-1687, two_phase_graph.py,
+                                                            three_phase_graph.py): [vel, pos, goal, type] in world coordinates */
         for (int k = 0; k < E; ++k) {
             double kx, ky, kvx = 0.0, kvy = 0.0; ent_pos(v, k, &kx, &ky);
             if (k < A) agent_vel(v, k, &kvx, &kvy);
@@ -733,6 +733,7 @@ static void graph_observation(envv* v, int i, double* node) {
         }
         goto mask;
     }
+    if (is_rotfam(&v->h->c)) { node_features_rot(v, i, node); goto mask; }
     {
     double evx, evy; agent_vel(v, i, &evx, &evy);
     const double px = v->x[i], py = v->y[i];

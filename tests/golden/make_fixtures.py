@@ -360,19 +360,19 @@ def main_rot(ROT="nav_graph_metered_single_corridor_rot_inv", prefix="rotinv", s
               "max phase", int(d["obs"][:, :, phase_col].max()), "phase_reached", d["st_phase_reached"].max(axis=0), "cooldown max", d["st_cooldown"].max())
 
 
-def main_global():
-    # graph_feat_type='global' (_get_entity_feat_global, …_july.py:1672-1691): node rows [vel, pos, goal, type] in world coordinates, F = 7
-    seed = 5
-    for A, T, ws, el, guided in [(3, 60, 4.0, 25, False), (6, 120, 3.0, 60, True)]:
+def main_global(scenario_name="nav_metered_one_goal_graph_rotate_tube_july", prefix="julyglobal", seed=5,
+                jobs=((3, 60, 4.0, 25, False), (6, 120, 3.0, 60, True))):
+    # graph_feat_type='global' (_get_entity_feat_global, …_july.py:1672-1691; rot_inv.py:1668-1687): node rows [vel, pos, goal, type] in world coordinates, F = 7
+    for A, T, ws, el, guided in jobs:
         while True:                                   # the reference crashes at construction for some seeds (see main_rot)
             seed += 1
             try:
-                d = july_rollout(A, seed, T, world_size=ws, episode_length=el, guided=guided, graph_feat_type="global")
+                d = july_rollout(A, seed, T, world_size=ws, episode_length=el, guided=guided, graph_feat_type="global", scenario_name=scenario_name)
                 break
             except AttributeError as e:
                 print("seed", seed, "reference crashed:", str(e)[:70])
         d["graph_feat_type"] = "global"
-        p = os.path.join(HERE, "julyglobal_A%d_s%d%s.npz" % (A, seed, "_guided" if guided else ""))
+        p = os.path.join(HERE, "%s_A%d_s%d%s.npz" % (prefix, A, seed, "_guided" if guided else ""))
         np.savez_compressed(p, **d)
         print(p, os.path.getsize(p), "node row width", d["node"].shape[-1], "resets", int(d["did_reset"].sum()),
               "steps with a done agent", int(d["st_status"].any(axis=1).sum()), "phase_reached", d["st_phase_reached"].max(axis=0))
@@ -388,11 +388,14 @@ def main_blocks():
 def main(which):
     """`python make_fixtures.py [july|rot|phase|blocks ...]` regenerates the named groups (default: all)."""
     H.selfcheck_uniform_patch()
-    which = which or ["july", "global", "rot", "phase", "blocks"]
+    which = which or ["july", "global", "globalrot", "rot", "phase", "blocks"]
     if "july" in which:
         main_july()
     if "global" in which:
         main_global()
+    if "globalrot" in which:
+        main_global("nav_graph_metered_single_corridor_rot_inv", "rotinvglobal", seed=60, jobs=((4, 110, 2.4, 50, True),))
+        main_global("two_phase_graph", "twophaseglobal", seed=70, jobs=((3, 70, 4.0, 25, False),))
     if "rot" in which:
         main_rot()
     if "phase" in which:

@@ -16,7 +16,7 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-JULY = [q for pre in ("july", "julyglobal", "rotinv", "twophase", "threephase") for q in sorted(glob.glob(os.path.join(GOLD, pre + "_A*_s*.npz")))]
+JULY = [q for pre in ("july", "julyglobal", "rotinv", "twophase", "threephase", "rotinvglobal", "twophaseglobal") for q in sorted(glob.glob(os.path.join(GOLD, pre + "_A*_s*.npz")))]
 ROT = "nav_graph_metered_single_corridor_rot_inv"
 ROTFAM = [ROT, "two_phase_graph", "three_phase_graph"]
 TOL = 1e-5

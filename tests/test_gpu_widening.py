@@ -20,7 +20,10 @@ JULY = "nav_metered_one_goal_graph_rotate_tube_july"
     dict(scenario_name=JULY, num_envs=17, num_agents=3, world_size=4.0, episode_length=7, seed=102),
     dict(scenario_name="navigation_graph", num_envs=33, num_agents=6, num_obstacles=3, num_walls=4, world_size=3.0, episode_length=8, seed=103),
     dict(scenario_name="navigation_graph", num_envs=40, num_agents=10, world_size=4.0, episode_length=8, seed=104),
-], ids=["july-A10", "july-A3", "nav-walls", "nav-A10"])
+    dict(scenario_name="nav_graph_metered_single_corridor_rot_inv", num_envs=40, num_agents=10, world_size=4.0, episode_length=8, seed=105),
+    dict(scenario_name="two_phase_graph", num_envs=25, num_agents=4, world_size=3.0, episode_length=8, seed=106),
+    dict(scenario_name="three_phase_graph", num_envs=25, num_agents=10, world_size=4.0, episode_length=8, seed=107),
+], ids=["july-A10", "july-A3", "nav-walls", "nav-A10", "rotinv-A10", "twophase-A4", "threephase-A10"])
 def test_global_graph_features_vs_oracle(kw):
     cfg = gmpe.make_config(graph_feat_type="global", **kw)
     assert cfg.node_feats == 7

@@ -135,9 +135,8 @@ def test_config_from_args_mirrors_reference_fields():
     assert cg.graph_feat_type == 1 and cg.node_feats == 7 and gcfg.algorithmic_bytes_per_env_step(cg) == 24250 - 4 * 10 * 20
     a.graph_feat_type = "relative"
     a.scenario_name = "two_phase_graph"
-    a.graph_feat_type = "global"
-    with pytest.raises(NotImplementedError):
-        gmpe.config_from_args(a)
+    a.graph_feat_type = "global"                             # the rot_inv family has the same _get_entity_feat_global (rot_inv.py:1668-1687)
+    assert gmpe.config_from_args(a).node_feats == 7
     a.graph_feat_type = "relative"
     c3 = gmpe.config_from_args(a)
     assert (c3.obs_dim, c3.node_feats, c3.n_actions) == (15, 7, 25)
