@@ -268,6 +268,24 @@ def main():
         cl_el, cl_ms = sorted(cl)[1]
         closed = {"ms_per_step": cl_ms / kc, "steps": kc, "launches": kc,
                   "what": "one k_env launch per step (hipGraph of K kernel nodes), same buffers: launch + latency chain + drain per step"}
+    # ---- side measurement: the same rollout into slot-per-step storage [T, ...] (what DeviceRolloutBuffer.collect does). With ONE slot every
+    # step overwrites the same 98 MB, which the 256 MiB Infinity Cache can absorb; T slots (2.5 GB at c2) cannot be, so this is the figure that
+    # is certainly paid in HBM writes. Only where T slots fit comfortably (c2 / c3-sized outputs).
+    slotted = None
+    if mode == "rollout" and slots is None and not args.no_closed_loop and world == 1:
+        T = 26
+        o = eng.out
+        keys = [k for k in StepOutputs.__slots__ if getattr(o, k) is not None]
+        step_bytes = sum(getattr(o, k).numel() * getattr(o, k).element_size() for k in keys)
+        if step_bytes * T < (8 << 30):
+            st = {k: torch.empty((T,) + tuple(getattr(o, k).shape), dtype=getattr(o, k).dtype, device=dev) for k in keys}
+            roll_T = lambda kk: eng.rollout(actions, kk, slot0=StepOutputs(**{k: v[0] for k, v in st.items()}), num_slots=T,
+                                            strides={k: v[0].numel() for k, v in st.items()})
+            roll_T(K); torch.cuda.synchronize(dev)
+            sl = sorted(timed(roll_T, K) for _ in range(3))[1]
+            slotted = {"slots": T, "ms_per_step": sl[1] / K, "steps": K, "launches": 1, "bytes_written_per_pass_over_the_slots": step_bytes * T,
+                       "what": "ONE launch of the rollout kernel, step k written to slot k % 26 of [26, ...] storage (nontemporal graph stores)"}
+            del st
     # separate pass: per-launch events (isolated kernel duration incl. event overhead)
     iso = None
     if mode != "rollout" or not args.no_closed_loop:
@@ -353,6 +371,10 @@ def main():
                          "isolated_launch_ms": iso,
                          "algorithmic_bytes_per_env_step": B, "env_steps_per_launch": env_steps_per_launch},
         }
+        if slotted is not None:
+            slotted["frac"] = B * n_envs / (slotted["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            slotted["env_steps_per_s"] = n_envs / (slotted["ms_per_step"] * 1e-3)
+            out["rollout_into_slots"] = slotted
         if closed is not None:
             closed["frac"] = B * n_envs / (closed["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             closed["env_steps_per_s"] = n_envs / (closed["ms_per_step"] * 1e-3)
