@@ -22,7 +22,7 @@ def _bench(*flags):
 def test_default_line_has_every_contract_field():
     d = _bench("--no-cpu-baseline", "--reps", "3")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "repetitions", "closed_loop", "numpy_boundary"):   # cpu_baseline: next test
+              "vs_baseline", "dtype", "data", "config", "roofline", "repetitions", "closed_loop", "rollout_into_slots", "numpy_boundary"):   # cpu_baseline: next test
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 3 and d["higher_is_better"] is True
     assert d["unit"] == "env-steps/s" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
@@ -41,6 +41,7 @@ def test_default_line_has_every_contract_field():
     rp = d["repetitions"]
     assert rp["n"] == 3 and len(rp["env_steps_per_s"]) == 3 and sorted(rp["env_steps_per_s"])[1] == d["value"]   # the median is reported
     assert d["closed_loop"]["launches"] == 20 and d["closed_loop"]["ms_per_step"] > 0
+    assert d["rollout_into_slots"]["slots"] == 26 and d["rollout_into_slots"]["launches"] == 1 and 0 < d["rollout_into_slots"]["frac"] < 1
     assert d["numpy_boundary"]["value"] > 1e5 and d["numpy_boundary"]["value"] < d["value"]
     assert d["value"] > 1e6                                  # BASELINE.json target on one MI355X
 
