@@ -152,6 +152,11 @@ def test_step_many_takes_the_rollout_kernel_and_falls_back(monkeypatch):
     for k in OUT_KEYS:
         assert torch.equal(getattr(o1, k), getattr(o2, k)), k
     _compare_state(e1, e2, "roll vs loop")
+    for K in (1, 2, 1, 3):                                   # degenerate rollouts: a single step is load -> step -> write-back in one pass of the loop
+        o1, o2 = e1.step_many(acts, K), e2.step_many(acts, K)
+        for k in OUT_KEYS:
+            assert torch.equal(getattr(o1, k), getattr(o2, k)), (K, k)
+        _compare_state(e1, e2, "K=%d" % K)
 
 
 @pytest.mark.parametrize("compact", [False, True])
