@@ -1,5 +1,6 @@
-// gmpe_step.hip — host side of libgmpe.so: the C ABI of include/gmpe.h, state allocation, tile-shape selection, launches,
-// hipGraph replay of open-loop rollouts, timing hooks, and the three small edge-compaction kernels (process_adj).
+// gmpe_step.hip — host side of libgmpe.so: the C ABI of include/gmpe.h, state allocation, tile-shape selection, launches, the split
+// big-E pipeline, hipGraph replay of per-step launch sequences, timing hooks, and the small streaming kernels around the fused one
+// (adjacency expansion, edge compaction, rollout-buffer masks).
 //
 // The fused GraphMPE step / reset kernel lives in gmpe_kernel.h (template k_env<BLOCK, AP, SC, FL>) and is instantiated per
 // scenario variant by gmpe_sc.hip. A workgroup (tile) owns G consecutive environments; everything the reference does for one
@@ -9,7 +10,11 @@
 //   load SoA state -> LDS | decode action + integrate (closed-form unicycle, or MPE soft-contact forces, pair-parallel) |
 //   all-pairs distances | phase FSM + goal reach (parallel restatement of the sequential agent loop, SURVEY.md §8a
 //   "ordered-visibility rule") | graph stores (adj [A,E,E], node_obs [A,E,F]: 16-byte coalesced) by waves 1.. while wave 0
-//   does reward / done / info / write-back | optional reset (serial rejection sampler on one lane per env).
+//   does reward / done / info / write-back | optional reset (wave-cooperative rejection sampler).
+//
+// Launch shapes: gmpe_step = one launch of the step instantiation (FL 0 / 1); gmpe_rollout_steps / gmpe_step_many = ONE
+// launch of the rollout instantiation (FL 2) for K steps, state carried in LDS / registers; handles on the split big-E path run
+// k_env -> compact [N,E,E] scratch -> k_adj_expand -> [N,A,E,E], chunk-pipelined on side streams.
 //
 // HBM-bound by construction: per env-step the kernel reads ~1 KB of state and writes 4·A·(E² + F·E + D + 2) bytes of fp32
 // observations; no MFMA (there is no contraction here). All geometry is fp64 with contraction OFF so thresholds see the

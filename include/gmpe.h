@@ -13,7 +13,8 @@
  *    No exception crosses the ABI.
  *  - "dev" pointers are device (HBM) pointers owned by the CALLER (e.g. torch tensors'
  *    data_ptr()); "host" pointers are ordinary host memory. The handle owns only the persistent
- *    SoA world state and a few KB of scratch; step/reset never allocate.
+ *    SoA world state and scratch (a few KB; plus one [N,E,E] float matrix for handles on the split
+ *    big-E path, allocated by gmpe_create); step/reset never allocate.
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream). step/reset are
  *    asynchronous on it; get/set_field synchronise the handle's stream themselves.
  *  - one handle per GPU; handles are not thread-safe.
