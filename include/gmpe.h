@@ -290,9 +290,11 @@ int gmpe_edges_from_adj_compact(gmpe_handle* h, const float* adj_compact_dev, in
  * the env are done. Either output may be NULL. */
 int gmpe_masks_from_dones(gmpe_handle* h, const uint8_t* done_dev, float* masks_dev, float* active_masks_dev, void* stream);
 
-/* What gmpe_create chose for this handle (recorded by bench.py next to every number). The GMPE_G / GMPE_BLOCK / GMPE_NT /
- * GMPE_SPEC / GMPE_SPLIT / GMPE_ROLL environment variables override the heuristics; none of them changes results
- * (tests/test_gpu_instantiations.py). */
+/* What gmpe_create chose for this handle (recorded by bench.py next to every number). Environment variables override the heuristics —
+ * GMPE_G / GMPE_BLOCK (step tile shape), GMPE_GROLL (rollout tile shape), GMPE_AP=0 (run-time-size instead of exact-size kernels),
+ * GMPE_NT / GMPE_ROLLNT (nontemporal graph stores of step / rollout launches), GMPE_SPEC (wave specialisation), GMPE_SPLIT / GMPE_CHUNKS
+ * (split big-E path and its chunk count), GMPE_ROLL (gmpe_step_many as one rollout launch) — none of them changes results
+ * (tests/test_gpu_instantiations.py, tests/test_gpu_rollout_kernel.py). */
 typedef struct gmpe_tuning {
     int32_t G;                  /* envs per workgroup (tile)                                               */
     int32_t block;              /* threads per workgroup: 64, 128 or 256                                   */
