@@ -177,3 +177,11 @@ def test_rollout_gather_real_engine(scen, mode):
         assert torch.equal(u["done"], o.done.bool()), t
     with pytest.raises(ValueError):
         RolloutGather(GmpeEngine(cfg), 1)                  # needs the compact adjacency
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _destroy_process_group_at_exit():
+    yield
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
