@@ -1,3 +1,5 @@
+"""Diagnostic: host <-> device copy paths a NumPy-boundary step uses (CPU writes into / reads from pinned memory, H2D from pinned / pageable / NumPy-owned memory,
+D2H into pinned) timed in isolation on the GPU box (not a benchmark)."""
 import sys, time, os, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 def t(f, n=10):

@@ -1,3 +1,6 @@
+"""Diagnostic: per-phase medians and maxima of BatchedGraphMPEVecEnv.step for the action formats a runner may pass (upload, launch, kernel, D2H, done cast, info clone).
+This is the script that found the ~90 ms CPU-quota throttling stalls caused by 128-thread torch CPU ops (profiles/r02_notes.md). NOGC=1 freezes the GC, SPIN=1 polls events
+instead of blocking in stream synchronize (both ruled out as causes)."""
 import sys, time, argparse, os, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 import gmpe, bench
