@@ -229,7 +229,10 @@ class GmpeEngine(object):
                                  % int((e & 2).astype(bool).sum()))
 
     # ------------------------------------------------------------------ edges (learner-side process_adj)
-    def edges_from_adj(self, adj, max_edge_dist, inclusive=False, cap=None):
+    def edges_from_adj(self, adj, max_edge_dist, inclusive=False, cap=None, index64=False):
+        """process_adj's edge set (gnn_new.py:329-358) of a materialised [B, E, E] (or [N, A, E, E]) adjacency: -> (edge_index [2, M] int32 — int64
+        with index64=True, what torch.nonzero / PyG message passing use —, edge_attr [M], M). Prefer edges_from_adj_compact when the
+        engine writes the compact adjacency: it reads 1/A of the bytes."""
         adj = adj.reshape(-1, adj.shape[-2], adj.shape[-1]).contiguous()
         B, E = adj.shape[0], adj.shape[-1]
         cap = int(cap if cap is not None else B * E * E)
@@ -240,7 +243,8 @@ class GmpeEngine(object):
                                                 ei.data_ptr(), ea.data_ptr(), cap, ne.data_ptr(), self._stream()),
                    "gmpe_edges_from_adj")
         m = int(ne.item())
-        return ei[:, :min(m, cap)], ea[:min(m, cap)], m
+        ei = ei[:, :min(m, cap)]
+        return (ei.long() if index64 else ei), ea[:min(m, cap)], m
 
     def edges_from_adj_compact(self, adj_compact, copies, max_edge_dist, inclusive=False, cap=None, index64=True):
         """process_adj's edge set (gnn_new.py:329-358) for the [N*copies, E, E] batch the runner feeds the GNN, computed from the
