@@ -502,7 +502,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
             ok = ok && hipStreamCreateWithFlags(&h->exp_st, hipStreamNonBlocking) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
             for (int q2 = 0; q2 < 3 && ok; ++q2) ok = hipEventCreateWithFlags(&h->ev_join[q2], hipEventDisableTiming) == hipSuccess;
-            h->ev_chunk.resize((size_t)h->chunks, nullptr);
+            h->ev_chunk.resize((size_t)h->chunks + 2, nullptr);
             for (size_t q2 = 0; q2 < h->ev_chunk.size() && ok; ++q2) ok = hipEventCreateWithFlags(&h->ev_chunk[q2], hipEventDisableTiming) == hipSuccess;
             if (!ok) { gmpe_destroy(h); return fail(GMPE_ERR_HIP, "split path: could not create the side streams / events"); }
         }
@@ -653,9 +653,20 @@ static int split_pipeline(gmpe_handle* h, int mode, KParams& p, float* adj_full,
     p.o.adj = h->adj_scratch; p.o.adj_compact = 1;
     HIPCHK(hipEventRecord(h->ev_fork, st));
     for (hipStream_t s : {h->env_st[0], h->env_st[1], h->exp_st}) HIPCHK(hipStreamWaitEvent(s, h->ev_fork, 0));
-    for (int c = 0; c < C; ++c) {
-        const int lo = c * per, hi = lo + per < N ? lo + per : N;
-        if (lo >= hi) break;
+    // chunk boundaries: equal chunks, except that the first two are a quarter and a half chunk (GMPE_RAMP) so that the expansion stream — the
+    // bottleneck — starts after a quarter of a k_env chunk instead of a whole one
+    int bounds[130]; int nb = 0;
+    {
+        const bool ramp = !(getenv("GMPE_RAMP") && !atoi(getenv("GMPE_RAMP"))) && per >= 4 * h->G;   // default on; GMPE_RAMP=0: equal chunks
+        int lo = 0;
+        if (ramp) { const int q = (per / 4 + h->G - 1) / h->G * h->G; bounds[nb++] = lo; lo += q; bounds[nb++] = lo; lo += 2 * q; }
+        while (lo < N && nb < 129) { bounds[nb++] = lo; lo += per; }
+        bounds[nb] = N;
+        for (int q = 0; q < nb; ++q) if (bounds[q] > N) bounds[q] = N;
+    }
+    for (int c = 0; c < nb && c < (int)h->ev_chunk.size(); ++c) {
+        const int lo = bounds[c], hi = bounds[c + 1];
+        if (lo >= hi) continue;
         hipStream_t se = h->env_st[c & 1];
         p.env_lo = lo; p.env_hi = hi;
         dispatch_env(h, h->block, ap_of(h), fl, se, p);

@@ -293,7 +293,7 @@ int gmpe_masks_from_dones(gmpe_handle* h, const uint8_t* done_dev, float* masks_
 /* What gmpe_create chose for this handle (recorded by bench.py next to every number). Environment variables override the heuristics —
  * GMPE_G / GMPE_BLOCK (step tile shape), GMPE_GROLL (rollout tile shape), GMPE_AP=0 (run-time-size instead of exact-size kernels),
  * GMPE_NT / GMPE_ROLLNT (nontemporal graph stores of step / rollout launches), GMPE_SPEC (wave specialisation), GMPE_SPLIT / GMPE_CHUNKS
- * (split big-E path and its chunk count), GMPE_ROLL (gmpe_step_many as one rollout launch) — none of them changes results
+ * / GMPE_RAMP (split big-E path, its chunk count, quarter + half first chunks), GMPE_ROLL (gmpe_step_many as one rollout launch) — none of them changes results
  * (tests/test_gpu_instantiations.py, tests/test_gpu_rollout_kernel.py). */
 typedef struct gmpe_tuning {
     int32_t G;                  /* envs per workgroup (tile)                                               */
