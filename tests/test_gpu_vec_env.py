@@ -185,3 +185,14 @@ def _destroy_process_group_at_exit():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
+
+
+def test_example_runner_loop_runs_both_paths():
+    """examples/runner_loop.py: the reference runner's collect loop over the drop-in vec env and over the device-resident buffer."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("runner_loop", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "runner_loop.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    a, b = mod.main(["--envs", "48", "--agents", "4", "--episode-length", "8", "--episodes", "2"])
+    assert a["shapes"]["adj"] == (48, 4, 8, 8) and a["info_keys"] >= 17 and a["env_steps_per_s"] > 0
+    assert b["shapes"]["adj"] == (9, 48, 4, 8, 8) and b["edges_last_slot"] >= 0 and b["env_steps_per_s"] > 0
