@@ -240,6 +240,8 @@ struct gmpe_handle {
     hipStream_t env_st[2] = {nullptr, nullptr}, exp_st = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_chunk;
+    std::vector<hipEvent_t> ev_exp;      // expansion of chunk c finished (back-pressure on the k_env streams)
+    int ahead = 0;                       // k_env may run at most this many chunks ahead of the expansion (0: unbounded)
     unsigned long long* stamps = nullptr;
     hipEvent_t region_ev[2] = {nullptr, nullptr};
     int32_t* edge_ws = nullptr;      // [cap_graphs] counts | [cap_graphs] offsets | [cap_graphs/1024+2] chunk sums
@@ -473,14 +475,14 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     {
         const double out_bytes = (double)N * h->A * ((double)E * E + 8.0 * E) * 4.0;
         h->nt = getenv("GMPE_NT") ? atoi(getenv("GMPE_NT")) : (out_bytes > 192.0 * 1024 * 1024 ? 1 : 0);
-        // Split path (fused kernel -> compact matrix, k_adj_expand -> A copies, chunk-pipelined; see split_pipeline): measured to pay only
-        // in a narrow regime — adjacency >= ~95 % of the bytes (A >= 48) AND a launch of at most ~8 rounds of resident tiles: c5 per-GPU
-        // shard (2048 envs x 64 agents) 1522 us split vs 1731 fused, but 4096 envs 3658 vs 3373, 16384 envs 15.8 vs 13.0 ms; c4 (A = 32)
-        // 1252 vs 1177 (profiles/README.md). Everything else runs the fused kernel.
+        // Split path (fused kernel -> compact matrix, k_adj_expand -> A copies, chunk-pipelined; see split_pipeline): pays where the
+        // adjacency is >= ~95 % of the bytes (A >= 48): c5 shapes (64 agents) 2048 envs 1515 us split vs 1731 fused, 4096: 2994 vs 3455,
+        // 8192: 6043 vs 6565, 16384: 11618 vs 12981 (with the run-ahead bound below); c4 (A = 32) 1260 vs 1132: stays fused
+        // (profiles/r02_notes.md). Everything else runs the fused kernel.
         const size_t tiles_resident = (size_t)dev_cus * (size_t)[&] { const int q = sc_dispatch_occ(sc_of(h->c), block_sel ? block_sel : 256, ap_sel, lds_bytes(G, h->A, E, h->D, cfg->num_walls)); return q > 0 ? q : 1; }();
         const size_t tiles_total = (N + G - 1) / G;
         h->split = getenv("GMPE_SPLIT") ? atoi(getenv("GMPE_SPLIT"))
-                                        : (out_bytes > 192.0 * 1024 * 1024 && h->A >= 48 && tiles_total <= 8 * tiles_resident ? 1 : 0);
+                                        : (out_bytes > 192.0 * 1024 * 1024 && h->A >= 48 ? 1 : 0);
         if ((uint64_t)N * E * E >= (1ull << 32)) h->split = 0;            // k_adj_expand indexes the compact matrix with 32 bits
         h->roll = getenv("GMPE_ROLL") ? atoi(getenv("GMPE_ROLL")) : 1;
         if ((uint64_t)h->A * E * E / 4 * (E * E / 4 + 1) >= (1ull << 32)) h->split = 0;   // k_adj_expand's exact magic division
@@ -504,6 +506,16 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
             for (int q2 = 0; q2 < 3 && ok; ++q2) ok = hipEventCreateWithFlags(&h->ev_join[q2], hipEventDisableTiming) == hipSuccess;
             h->ev_chunk.resize((size_t)h->chunks + 2, nullptr);
             for (size_t q2 = 0; q2 < h->ev_chunk.size() && ok; ++q2) ok = hipEventCreateWithFlags(&h->ev_chunk[q2], hipEventDisableTiming) == hipSuccess;
+            h->ev_exp.resize(h->ev_chunk.size(), nullptr);
+            for (size_t q2 = 0; q2 < h->ev_exp.size() && ok; ++q2) ok = hipEventCreateWithFlags(&h->ev_exp[q2], hipEventDisableTiming) == hipSuccess;
+            // Back-pressure: the fused kernel is the faster stage, and left alone it runs many chunks ahead; by the time k_adj_expand reads a
+            // chunk's matrices they have left the 256 MiB Infinity Cache, and its A re-reads per matrix (one per ego copy, spread over the
+            // XCDs' L2s) come from HBM: 220 us per 256-env chunk instead of 150 (rocprofv3 trace, profiles/r02_notes.md). With k_env(c)
+            // waiting for expand(c - 2) the live part of the scratch stays cache-resident: c5 shapes 4096 envs 3640 -> 2994 us, 8192
+            // 7744 -> 6043, 16384 16003 -> 11618. A scratch that fits the cache as a whole (the 2048-env shard: 134 MB) needs no bound.
+            h->ahead = (double)N * E * E * sizeof(float) > 192.0 * 1024 * 1024 ? 2 : 0;
+            if (getenv("GMPE_AHEAD")) h->ahead = atoi(getenv("GMPE_AHEAD"));
+            if (h->ahead < 0) h->ahead = 0;
             if (!ok) { gmpe_destroy(h); return fail(GMPE_ERR_HIP, "split path: could not create the side streams / events"); }
         }
     }
@@ -547,6 +559,8 @@ int gmpe_destroy(gmpe_handle* h) {
         for (hipStream_t s : {h->env_st[0], h->env_st[1], h->exp_st}) if (s) (void)hipStreamDestroy(s);
         for (hipEvent_t e : {h->ev_fork, h->ev_join[0], h->ev_join[1], h->ev_join[2]}) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : h->ev_chunk) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : h->ev_exp) if (e) (void)hipEventDestroy(e);
+        h->ev_exp.clear();
         h->ev_chunk.clear();
     }
     if (!h) return GMPE_OK;
@@ -669,6 +683,7 @@ static int split_pipeline(gmpe_handle* h, int mode, KParams& p, float* adj_full,
         if (lo >= hi) continue;
         hipStream_t se = h->env_st[c & 1];
         p.env_lo = lo; p.env_hi = hi;
+        if (h->ahead > 0 && c >= h->ahead) HIPCHK(hipStreamWaitEvent(se, h->ev_exp[c - h->ahead], 0));
         dispatch_env(h, h->block, ap_of(h), fl, se, p);
         HIPCHK(hipEventRecord(h->ev_chunk[c], se));
         HIPCHK(hipStreamWaitEvent(h->exp_st, h->ev_chunk[c], 0));
@@ -676,6 +691,7 @@ static int split_pipeline(gmpe_handle* h, int mode, KParams& p, float* adj_full,
         if ((EE & 3) == 0) hipLaunchKernelGGL(k_adj_expand, dim3(((uint32_t)h->A * (EE / 4) + 255) / 256, gy), dim3(256), 0, h->exp_st,
                                               h->adj_scratch, adj_full, lo, hi, EE / 4, h->A, magic_of(EE / 4));
         else hipLaunchKernelGGL(k_adj_expand1, dim3(((uint32_t)h->A * EE + 255) / 256, gy), dim3(256), 0, h->exp_st, h->adj_scratch, adj_full, lo, hi, EE, h->A);
+        if (h->ahead > 0) HIPCHK(hipEventRecord(h->ev_exp[c], h->exp_st));
     }
     int q = 0;
     for (hipStream_t s : {h->env_st[0], h->env_st[1], h->exp_st}) { HIPCHK(hipEventRecord(h->ev_join[q], s)); HIPCHK(hipStreamWaitEvent(st, h->ev_join[q], 0)); ++q; }
@@ -744,6 +760,7 @@ int gmpe_get_tuning(const gmpe_handle* h, gmpe_tuning* t) {
     t->G = h->G; t->block = h->block; t->nt = h->nt; t->spec = h->spec; t->split = h->split; t->roll = h->roll; t->ap = ap_of(h);
     t->lds_bytes = (int32_t)lds_bytes(h->G, h->A, h->E, h->D, h->c.num_walls);
     t->G_roll = h->G_roll; t->block_roll = h->block_roll;
+    t->chunks = h->split ? h->chunks : 0; t->ahead = h->split ? h->ahead : 0;
 #ifdef GMPE_DIAG
     t->diag_build = 1;
 #endif

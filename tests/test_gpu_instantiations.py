@@ -83,36 +83,37 @@ def test_navigation_graph_configs0_three_agents_one_env():
     assert _rollout_vs_oracle(cfg, 30, seed=66) >= 37
 
 
-def _full_size_slice(cfg_kw, n_total, n_slice, steps, act_seed):
-    """Full-size launch vs an oracle run of its first n_slice envs, every step; returns the last engine outputs."""
+def _full_size_slice(cfg_kw, n_total, n_slice, steps, act_seed, base=0):
+    """Full-size launch vs an oracle run of n_slice of its envs (the first ones, or those from `base` on), every step; returns the
+    last engine outputs."""
     import torch
     cfg = gmpe.make_config(num_envs=n_total, **cfg_kw)
-    small = gmpe.make_config(num_envs=n_slice, **cfg_kw)
+    small = gmpe.make_config(num_envs=n_slice, env_id_base=base, **cfg_kw)
     eng, orc = _engine(cfg), ol.Oracle(small)
     eo, oo = eng.reset(), orc.reset()
-    np.testing.assert_allclose(_np(eo.obs[:n_slice]), oo[0], rtol=0, atol=TOL)
-    np.testing.assert_allclose(_np(eo.node_obs[:n_slice]), oo[2], rtol=0, atol=TOL)
+    np.testing.assert_allclose(_np(eo.obs[base:base + n_slice]), oo[0], rtol=0, atol=TOL)
+    np.testing.assert_allclose(_np(eo.node_obs[base:base + n_slice]), oo[2], rtol=0, atol=TOL)
     g = torch.Generator(device="cpu"); g.manual_seed(act_seed)
     A, E = cfg.num_agents, cfg.num_entities
     n_resets = 0
     for t in range(steps):
         act = torch.randint(0, cfg.n_actions, (n_total, A), generator=g, dtype=torch.int32)
         o = eng.step(act)
-        oo = orc.step(act[:n_slice].numpy())
+        oo = orc.step(act[base:base + n_slice].numpy())
         n_resets += int(oo[7].sum())
         lab = "t=%d" % t
-        np.testing.assert_allclose(_np(o.obs[:n_slice]), oo[0], rtol=0, atol=TOL, err_msg=lab + " obs")
-        np.testing.assert_allclose(_np(o.node_obs[:n_slice]), oo[2], rtol=0, atol=TOL, err_msg=lab + " node")
-        adj = _np(o.adj[:n_slice])
+        np.testing.assert_allclose(_np(o.obs[base:base + n_slice]), oo[0], rtol=0, atol=TOL, err_msg=lab + " obs")
+        np.testing.assert_allclose(_np(o.node_obs[base:base + n_slice]), oo[2], rtol=0, atol=TOL, err_msg=lab + " node")
+        adj = _np(o.adj[base:base + n_slice])
         np.testing.assert_allclose(adj, np.broadcast_to(oo[3][:, None], adj.shape), rtol=0, atol=TOL, err_msg=lab + " adj")
         np.testing.assert_array_equal(adj == 0, np.broadcast_to(oo[3][:, None] == 0, adj.shape), err_msg=lab + " adj mask")
-        np.testing.assert_allclose(_np(o.reward[:n_slice]), oo[4], rtol=0, atol=TOL, err_msg=lab + " rew")
-        np.testing.assert_array_equal(_np(o.done[:n_slice]).astype(bool), oo[5], err_msg=lab + " done")
-        np.testing.assert_allclose(_np(o.info[:n_slice]), oo[6], rtol=2e-6, atol=2e-5, err_msg=lab + " info")
+        np.testing.assert_allclose(_np(o.reward[base:base + n_slice]), oo[4], rtol=0, atol=TOL, err_msg=lab + " rew")
+        np.testing.assert_array_equal(_np(o.done[base:base + n_slice]).astype(bool), oo[5], err_msg=lab + " done")
+        np.testing.assert_allclose(_np(o.info[base:base + n_slice]), oo[6], rtol=2e-6, atol=2e-5, err_msg=lab + " info")
     for f in ("x", "y", "s2", "s3"):
-        np.testing.assert_allclose(eng.get(f)[:n_slice], orc.get(f), rtol=0, atol=1e-9, err_msg=f)
+        np.testing.assert_allclose(eng.get(f)[base:base + n_slice], orc.get(f), rtol=0, atol=1e-9, err_msg=f)
     for f in ("status", "rng_ctr", "current_step", "goal_tracker", "n_agent_coll", "n_obst_coll"):
-        np.testing.assert_array_equal(eng.get(f)[:n_slice], orc.get(f), err_msg=f)
+        np.testing.assert_array_equal(eng.get(f)[base:base + n_slice], orc.get(f), err_msg=f)
     eng.check_errors()
     return eng, o, n_resets
 
@@ -153,22 +154,24 @@ def test_full_size_c4_with_oracle_slice():
     _graph_invariants(o, 32, 72, 8)
 
 
-def test_full_size_c5_shard_with_oracle_slice():
-    """configs[4], one GPU's shard of 8: 2048 envs x 64 agents, E = 128 (8.6 GB of adjacency per step)."""
+@pytest.mark.parametrize("n_envs,ahead", [(2048, 0), (4096, 2)], ids=["shard-2048", "4096-bounded-run-ahead"])
+def test_full_size_c5_shard_with_oracle_slice(n_envs, ahead):
+    """configs[4], one GPU's shard of 8: 2048 envs x 64 agents, E = 128 (8.6 GB of adjacency per step) — the split pipeline; and twice
+    that, where the compact-matrix scratch outgrows the Infinity Cache and the fused kernel is held to two chunks ahead of the expansion."""
     eng, o, n_resets = _full_size_slice(dict(scenario_name="navigation_graph", num_agents=64, world_size=12.0, episode_length=5, seed=1234),
-                                        2048, 128, 8, 44)
+                                        n_envs, 128, 8, 44, base=n_envs - 128 if ahead else 0)   # the big case checks the LAST chunk's envs
     assert n_resets >= 128
     t = eng.tuning()
-    assert t["nt"] == 1 or t["split"] == 1
+    assert t["split"] == 1 and t["ahead"] == ahead and t["chunks"] == n_envs // 256
     _graph_invariants(o, 64, 128, 8)
 
 
-@pytest.mark.parametrize("chunks", [1, 3, 8])
-def test_split_pipeline_across_steps_equals_step_loop(monkeypatch, chunks):
+@pytest.mark.parametrize("chunks,ahead", [(1, 0), (3, 1), (8, 0), (8, 2)])
+def test_split_pipeline_across_steps_equals_step_loop(monkeypatch, chunks, ahead):
     """gmpe_step_many on the split path (one chunk pipeline per step, any chunk count): same final outputs and state as one
     gmpe_step per step."""
     import torch
-    _knobs(monkeypatch, split=1, chunks=chunks)
+    _knobs(monkeypatch, split=1, chunks=chunks, ahead=ahead)
     cfg = gmpe.make_config(scenario_name="navigation_graph", num_envs=37, num_agents=12, num_obstacles=3, num_walls=4, world_size=5.0,
                            episode_length=6, seed=97)
     e1, e2 = _engine(cfg), _engine(cfg)
