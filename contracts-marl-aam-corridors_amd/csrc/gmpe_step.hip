@@ -492,8 +492,19 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
             if (e != hipSuccess) { gmpe_destroy(h); return fail(GMPE_ERR_HIP, std::string("hipMalloc(adjacency scratch): ") + hipGetErrorString(e)); }
             h->allocs.push_back(q);
             h->adj_scratch = static_cast<float*>(q);
-            // one chunk = about one full round of resident tiles (c5 shard of 2048 envs: 8 chunks of 256 envs)
-            h->chunks = (int)((tiles_total + tiles_resident - 1) / tiles_resident);
+            // Back-pressure: the fused kernel is the faster stage, and left alone it runs many chunks ahead; by the time k_adj_expand reads a
+            // chunk's matrices they have left the 256 MiB Infinity Cache, and its A re-reads per matrix (one per ego copy, spread over the
+            // XCDs' L2s) come from HBM: 220 us per 256-env chunk instead of 150 (rocprofv3 trace, profiles/r02_notes.md). With k_env(c)
+            // waiting for expand(c - 2) the live part of the scratch stays cache-resident: c5 shapes 4096 envs 3640 -> 2994 us, 8192
+            // 7744 -> 6043, 16384 16003 -> 11618. A scratch that fits the cache as a whole (the 2048-env shard: 134 MB) needs no bound.
+            h->ahead = (double)N * E * E * sizeof(float) > 192.0 * 1024 * 1024 ? 2 : 0;
+            if (getenv("GMPE_AHEAD")) h->ahead = atoi(getenv("GMPE_AHEAD"));
+            if (h->ahead < 0) h->ahead = 0;
+            // one chunk = one full round of resident tiles (c5 shard of 2048 envs: 8 chunks of 256 envs; 2 / 4 / 6 / 8 / 12 / 16 chunks: 1802 / 1602 /
+            // 1560 / 1522 / 1548 / 1539 us), two rounds when the run-ahead is bounded (long pipelines: fewer launch gaps on the expansion
+            // stream; 512- vs 256-env chunks: 4096 envs 2944-3029 vs 3104 us, 8192: 5729 vs 5828, 16384: 11223 vs 11521)
+            const size_t per_chunk = tiles_resident * (h->ahead > 0 ? 2 : 1);
+            h->chunks = (int)((tiles_total + per_chunk - 1) / per_chunk);
             if (h->chunks < 4) h->chunks = 4;
             if (h->chunks > 128) h->chunks = 128;
             if (getenv("GMPE_CHUNKS")) h->chunks = atoi(getenv("GMPE_CHUNKS"));
@@ -508,14 +519,6 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
             for (size_t q2 = 0; q2 < h->ev_chunk.size() && ok; ++q2) ok = hipEventCreateWithFlags(&h->ev_chunk[q2], hipEventDisableTiming) == hipSuccess;
             h->ev_exp.resize(h->ev_chunk.size(), nullptr);
             for (size_t q2 = 0; q2 < h->ev_exp.size() && ok; ++q2) ok = hipEventCreateWithFlags(&h->ev_exp[q2], hipEventDisableTiming) == hipSuccess;
-            // Back-pressure: the fused kernel is the faster stage, and left alone it runs many chunks ahead; by the time k_adj_expand reads a
-            // chunk's matrices they have left the 256 MiB Infinity Cache, and its A re-reads per matrix (one per ego copy, spread over the
-            // XCDs' L2s) come from HBM: 220 us per 256-env chunk instead of 150 (rocprofv3 trace, profiles/r02_notes.md). With k_env(c)
-            // waiting for expand(c - 2) the live part of the scratch stays cache-resident: c5 shapes 4096 envs 3640 -> 2994 us, 8192
-            // 7744 -> 6043, 16384 16003 -> 11618. A scratch that fits the cache as a whole (the 2048-env shard: 134 MB) needs no bound.
-            h->ahead = (double)N * E * E * sizeof(float) > 192.0 * 1024 * 1024 ? 2 : 0;
-            if (getenv("GMPE_AHEAD")) h->ahead = atoi(getenv("GMPE_AHEAD"));
-            if (h->ahead < 0) h->ahead = 0;
             if (!ok) { gmpe_destroy(h); return fail(GMPE_ERR_HIP, "split path: could not create the side streams / events"); }
         }
     }
