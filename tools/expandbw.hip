@@ -49,6 +49,19 @@ __global__ __launch_bounds__(256) void expandC(const v4f* __restrict__ src, v4f*
         for (int u = 0; u < UA; ++u) if (a0 + u < A) { if (NT) __builtin_nontemporal_store(val, d + (size_t)u * nq); else d[(size_t)u * nq] = val; }
     }
 }
+// X: like B, but XCD-aware: workgroups are dealt to the 8 XCDs round-robin by linear id, so workgroup L works for XCD L % 8; all workgroups
+// of one env are given to ONE XCD (env = 8 * (L / 8 / Bx) + L % 8), whose L2 then fetches the env's source matrix once instead of up to 8 times.
+template <bool NT>
+__global__ __launch_bounds__(256) void expandX(const v4f* __restrict__ src, v4f* __restrict__ dst, int N, uint32_t nq, int A, uint32_t Bx) {
+    const uint32_t L = blockIdx.x, xcd = L & 7u, idx = L >> 3;
+    const uint32_t el = idx / Bx, jb = idx - el * Bx;
+    const uint32_t n = el * 8u + xcd;
+    const uint32_t j = jb * 256u + threadIdx.x, per = (uint32_t)A * nq;
+    if (n >= (uint32_t)N || j >= per) return;
+    const uint32_t m = j % nq;
+    const v4f val = src[(size_t)n * nq + m];
+    if (NT) __builtin_nontemporal_store(val, dst + (size_t)n * per + j); else dst[(size_t)n * per + j] = val;
+}
 __global__ void fill4(v4f* __restrict__ dst, size_t n4, float v) {
     const v4f x = {v, v, v, v};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) __builtin_nontemporal_store(x, dst + i);
@@ -58,7 +71,7 @@ static uint32_t magic_of(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(0x1000000
 
 int main() {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    struct Shape { const char* name; int N, A, E; } shapes[] = {{"c4 8192x32x72", 8192, 32, 72}, {"c5 shard 2048x64x128", 2048, 64, 128}, {"c2 4096x10x20", 4096, 10, 20}};
+    struct Shape { const char* name; int N, A, E; } shapes[] = {{"c5 chunk 256x64x128", 256, 64, 128}, {"c5 shard 2048x64x128", 2048, 64, 128}, {"c5 8192x64x128 (src 512 MB)", 8192, 64, 128}, {"c4 8192x32x72", 8192, 32, 72}, {"c4 chunk 745x32x72", 745, 32, 72}};
     for (const Shape& s : shapes) {
         const uint32_t nq = (uint32_t)s.E * s.E / 4, total4 = (uint32_t)s.N * nq;
         const size_t out4 = (size_t)total4 * s.A;
@@ -76,10 +89,13 @@ int main() {
             return 0;
         };
         run("fill_nt grid 65536", [&] { fill4<<<65536, 256>>>(dst, out4, 1.f); });
+        { const uint32_t Bx = ((uint32_t)s.A * nq + 255) / 256; const uint32_t gX = 8u * ((s.N + 7) / 8) * Bx;
+          run("X nt (XCD-aware)", [&] { expandX<true><<<gX, 256>>>(src, dst, s.N, nq, s.A, Bx); });
+          run("X plain (XCD-aware)", [&] { expandX<false><<<gX, 256>>>(src, dst, s.N, nq, s.A, Bx); }); }
         run("A U=4 nt", [&] { expandA<4, true><<<(total4 + 255) / 256, 256>>>(src, dst, total4, nq, s.A); });
         run("A U=8 nt", [&] { expandA<8, true><<<(total4 + 255) / 256, 256>>>(src, dst, total4, nq, s.A); });
         run("A U=4 plain", [&] { expandA<4, false><<<(total4 + 255) / 256, 256>>>(src, dst, total4, nq, s.A); });
-        for (int gy : {64, 256, 1024}) {
+        for (int gy : {256, 1024}) {
             char lab[64];
             const dim3 gB(((uint32_t)s.A * nq + 255) / 256, gy < s.N ? gy : s.N);
             snprintf(lab, sizeof lab, "B nt gy=%d", gy);
