@@ -30,6 +30,7 @@ lib.gmpe_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 buf = np.zeros((8192, 16), dtype=np.uint64)
 nb = lib.gmpe_debug_stamps(eng.h, buf.ctypes.data_as(C.c_void_p), 8192)
 s = buf[:nb].astype(np.int64)
+s = s[s[:, 0] > 0]                                      # split path: every chunk launch stamps blocks 0..tiles-1 of ITS grid; the last chunk's rows survive
 names = ["S0 load", "S1 F-pass", "S2 dynamics", "S3 dist+static", "S4 phase/draw", "S5", "S6", "S7", "S8", "S9", "S10", "S11", "-"]
 d = np.diff(s[:, :13], axis=1)
 # v3 order in non-reset tiles: S0..S5 (load, F, dyn, dist, phase), then S9 (mask) S10 (adj) -> node -> S13/14/15 sec3 -> S6 -> sec4 -> S7 -> S11 obs -> S12
