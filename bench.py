@@ -57,7 +57,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
 HEADLINE_METRIC = "env-steps/sec (whole node) at 4096 envs x 10 agents, navigation_graph"     # BASELINE.json `metric` (configs[1] = c2)
 # Knobs that change which kernel instantiation / library runs. Performance knobs are recorded; result-changing ones are refused.
-PERF_KNOBS = ("GMPE_G", "GMPE_BLOCK", "GMPE_NT", "GMPE_SPEC", "GMPE_SPLIT", "GMPE_ROLL", "GMPE_GROLL", "GMPE_CHUNKS", "GMPE_RAMP", "GMPE_AP", "GMPE_ROLLNT", "GMPE_AHEAD")
+PERF_KNOBS = ("GMPE_G", "GMPE_BLOCK", "GMPE_NT", "GMPE_SPEC", "GMPE_SPLIT", "GMPE_ROLL", "GMPE_GROLL", "GMPE_CHUNKS", "GMPE_RAMP", "GMPE_AP", "GMPE_ROLLNT", "GMPE_AHEAD", "GMPE_XSTEP")
 DIAG_KNOBS = ("GMPE_ABLATE", "GMPE_LIB")
 
 
@@ -268,6 +268,14 @@ def main():
         cl_el, cl_ms = sorted(cl)[1]
         closed = {"ms_per_step": cl_ms / kc, "steps": kc, "launches": kc,
                   "what": "one k_env launch per step (hipGraph of K kernel nodes), same buffers: launch + latency chain + drain per step"}
+    if mode == "launch-loop" and tuning["split"] and tuning.get("xstep") and not args.no_closed_loop:
+        kc = min(K, 40)
+        host = lambda kk: [eng.step(actions[(W + k) % n_act_sets]) for k in range(kk)]
+        host(3); torch.cuda.synchronize(dev)
+        cl = [timed(host, kc) for _ in range(3)]
+        cl_el, cl_ms = sorted(cl)[1]
+        closed = {"ms_per_step": cl_ms / kc, "steps": kc, "launches": kc,
+                  "what": "one gmpe_step per step: the split pipeline forks from and joins into the caller's stream around EVERY step (what a policy-in-the-loop runner gets)"}
     # ---- side measurement: the same rollout into slot-per-step storage [T, ...] (what DeviceRolloutBuffer.collect does). With ONE slot every
     # step overwrites the same 98 MB, which the 256 MiB Infinity Cache can absorb; T slots (2.5 GB at c2) cannot be, so this is the figure that
     # is certainly paid in HBM writes. Only where T slots fit comfortably (c2 / c3-sized outputs).
@@ -359,7 +367,10 @@ def main():
                        "info": not args.no_info, "state_dtype": "f64", "outputs_dtype": "f32 / i32 / u8",
                        "launch": {"rollout": "ONE launch of the persistent rollout kernel for the K steps (gmpe_rollout_steps), outputs: "
                                              + ("%d slots [T, ...]" % args.slots if slots is not None else "one slot (every step overwrites the same buffers)"),
-                                  "launch-loop": "one launch per step from one C call" + (" (hipGraph of K kernel nodes)" if graph_ok else ""),
+                                  "launch-loop": ("ONE chunk pipeline over the K open-loop steps from one C call: k_env / k_adj_expand chunk launches of consecutive steps chained "
+                                                  "by per-chunk events, fork before the first step and join after the last (gmpe_step_many on the split path)"
+                                                  if tuning["split"] and tuning.get("xstep") and not args.adj_compact else
+                                                  "one launch per step from one C call" + (" (hipGraph of K kernel nodes)" if graph_ok else "")),
                                   "host-loop": "one launch per step, Python loop over gmpe_step"}[mode],
                        "tuning": tuning, "env": env_knobs, "diag": bool(args.diag),
                        "sharding": "env ranges, %d per GPU, no collective in step" % n_envs},

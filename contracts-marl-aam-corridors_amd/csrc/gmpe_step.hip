@@ -242,6 +242,8 @@ struct gmpe_handle {
     std::vector<hipEvent_t> ev_chunk;
     std::vector<hipEvent_t> ev_exp;      // expansion of chunk c finished (back-pressure on the k_env streams)
     int ahead = 0;                       // k_env may run at most this many chunks ahead of the expansion (0: unbounded)
+    int xstep = 0;                       // gmpe_step_many on the split path: chain the steps' pipelines (no join between steps)
+    int chunks_x = 1, ahead_x = 0;       // chunking / run-ahead bound of the chained pipeline
     unsigned long long* stamps = nullptr;
     hipEvent_t region_ev[2] = {nullptr, nullptr};
     int32_t* edge_ws = nullptr;      // [cap_graphs] counts | [cap_graphs] offsets | [cap_graphs/1024+2] chunk sums
@@ -500,6 +502,15 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
             h->ahead = (double)N * E * E * sizeof(float) > 192.0 * 1024 * 1024 ? 2 : 0;
             if (getenv("GMPE_AHEAD")) h->ahead = atoi(getenv("GMPE_AHEAD"));
             if (h->ahead < 0) h->ahead = 0;
+            // gmpe_step_many (open-loop steps): the steps' pipelines are chained — k_env(step s+1, chunk c) waits for expand(step s, chunk c), not for
+            // the whole step s — which hides the pipeline's fill: c5 shard 1486-1524 -> 1383 us per step, 16384 envs 11.26 -> 10.94 ms. The chained
+            // pipeline is long at any batch size, so it always uses two rounds of tiles per chunk and the run-ahead bound of 2 (shard: 8 chunks
+            // unbounded 1416, 4 chunks D = 2 1383, 3 / 5 / 6 chunks 1409 / 1410 / 1434; D = 1 1982, D = 3 1407).
+            h->xstep = getenv("GMPE_XSTEP") ? atoi(getenv("GMPE_XSTEP")) : 1;
+            h->chunks_x = (int)((tiles_total + 2 * tiles_resident - 1) / (2 * tiles_resident));
+            if (h->chunks_x < 2) h->chunks_x = 2;
+            if (h->chunks_x > 128) h->chunks_x = 128;
+            h->ahead_x = 2;
             // one chunk = one full round of resident tiles (c5 shard of 2048 envs: 8 chunks of 256 envs; 2 / 4 / 6 / 8 / 12 / 16 chunks: 1802 / 1602 /
             // 1560 / 1522 / 1548 / 1539 us), two rounds when the run-ahead is bounded (long pipelines: fewer launch gaps on the expansion
             // stream; 512- vs 256-env chunks: 4096 envs 2944-3029 vs 3104 us, 8192: 5729 vs 5828, 16384: 11223 vs 11521)
@@ -510,12 +521,15 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
             if (getenv("GMPE_CHUNKS")) h->chunks = atoi(getenv("GMPE_CHUNKS"));
             if (h->chunks < 1) h->chunks = 1;
             if ((size_t)h->chunks > N) h->chunks = (int)N;
+            if (getenv("GMPE_CHUNKS")) h->chunks_x = h->chunks;            // the knobs set both pipelines
+            if (getenv("GMPE_AHEAD")) h->ahead_x = h->ahead;
+            if ((size_t)h->chunks_x > N) h->chunks_x = (int)N;
             bool ok = true;
             for (int q2 = 0; q2 < 2 && ok; ++q2) ok = hipStreamCreateWithFlags(&h->env_st[q2], hipStreamNonBlocking) == hipSuccess;
             ok = ok && hipStreamCreateWithFlags(&h->exp_st, hipStreamNonBlocking) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
             for (int q2 = 0; q2 < 3 && ok; ++q2) ok = hipEventCreateWithFlags(&h->ev_join[q2], hipEventDisableTiming) == hipSuccess;
-            h->ev_chunk.resize((size_t)h->chunks + 2, nullptr);
+            h->ev_chunk.resize((size_t)(h->chunks > h->chunks_x ? h->chunks : h->chunks_x) + 2, nullptr);
             for (size_t q2 = 0; q2 < h->ev_chunk.size() && ok; ++q2) ok = hipEventCreateWithFlags(&h->ev_chunk[q2], hipEventDisableTiming) == hipSuccess;
             h->ev_exp.resize(h->ev_chunk.size(), nullptr);
             for (size_t q2 = 0; q2 < h->ev_exp.size() && ok; ++q2) ok = hipEventCreateWithFlags(&h->ev_exp[q2], hipEventDisableTiming) == hipSuccess;
@@ -662,14 +676,19 @@ static void dispatch_env(const gmpe_handle* h, int block, int ap, int fl, hipStr
 // streams let one chunk's last, partly filled round of tiles overlap the next chunk's first. Fork from / join into the caller's
 // stream. (Pipelining ACROSS steps as well — expansion of step k under k_env of step k+1, two scratch buffers — was built and
 // measured slower: with both kernels resident all the time the expansion runs at half speed, c4 1563 vs 1252 us; profiles/README.md.)
-static int split_pipeline(gmpe_handle* h, int mode, KParams& p, float* adj_full, hipStream_t st) {
+// `first` / `last`: gmpe_step_many_launches may chain the pipelines of consecutive steps without joining in between (fork before the first step, join after the
+// last): k_env(step s+1, chunk c) then waits for expand(step s, chunk c) — the reader of the scratch rows it overwrites — instead of for the whole step s.
+static int split_pipeline(gmpe_handle* h, int mode, KParams& p, float* adj_full, hipStream_t st, bool first = true, bool last = true) {
+    const bool chained = !(first && last);
     const uint32_t EE = (uint32_t)h->E * h->E;
-    const int N = h->c.num_envs, C = h->chunks;
+    const int N = h->c.num_envs, C = chained ? h->chunks_x : h->chunks, ahead = chained ? h->ahead_x : h->ahead;
     const int per = ((N + C - 1) / C + h->G - 1) / h->G * h->G;              // envs per chunk, a whole number of tiles
     const int fl = (mode == MODE_STEP && !h->nt && !h->ablate && h->spec) ? 1 : 0;
     p.o.adj = h->adj_scratch; p.o.adj_compact = 1;
-    HIPCHK(hipEventRecord(h->ev_fork, st));
-    for (hipStream_t s : {h->env_st[0], h->env_st[1], h->exp_st}) HIPCHK(hipStreamWaitEvent(s, h->ev_fork, 0));
+    if (first) {
+        HIPCHK(hipEventRecord(h->ev_fork, st));
+        for (hipStream_t s : {h->env_st[0], h->env_st[1], h->exp_st}) HIPCHK(hipStreamWaitEvent(s, h->ev_fork, 0));
+    }
     // chunk boundaries: equal chunks, except that the first two are a quarter and a half chunk (GMPE_RAMP) so that the expansion stream — the
     // bottleneck — starts after a quarter of a k_env chunk instead of a whole one
     int bounds[130]; int nb = 0;
@@ -686,7 +705,8 @@ static int split_pipeline(gmpe_handle* h, int mode, KParams& p, float* adj_full,
         if (lo >= hi) continue;
         hipStream_t se = h->env_st[c & 1];
         p.env_lo = lo; p.env_hi = hi;
-        if (h->ahead > 0 && c >= h->ahead) HIPCHK(hipStreamWaitEvent(se, h->ev_exp[c - h->ahead], 0));
+        if (ahead > 0 && c >= ahead) HIPCHK(hipStreamWaitEvent(se, h->ev_exp[c - ahead], 0));
+        if (chained && !first) HIPCHK(hipStreamWaitEvent(se, h->ev_exp[c], 0));   // the previous step's expansion of this chunk has read the scratch rows
         dispatch_env(h, h->block, ap_of(h), fl, se, p);
         HIPCHK(hipEventRecord(h->ev_chunk[c], se));
         HIPCHK(hipStreamWaitEvent(h->exp_st, h->ev_chunk[c], 0));
@@ -694,10 +714,12 @@ static int split_pipeline(gmpe_handle* h, int mode, KParams& p, float* adj_full,
         if ((EE & 3) == 0) hipLaunchKernelGGL(k_adj_expand, dim3(((uint32_t)h->A * (EE / 4) + 255) / 256, gy), dim3(256), 0, h->exp_st,
                                               h->adj_scratch, adj_full, lo, hi, EE / 4, h->A, magic_of(EE / 4));
         else hipLaunchKernelGGL(k_adj_expand1, dim3(((uint32_t)h->A * EE + 255) / 256, gy), dim3(256), 0, h->exp_st, h->adj_scratch, adj_full, lo, hi, EE, h->A);
-        if (h->ahead > 0) HIPCHK(hipEventRecord(h->ev_exp[c], h->exp_st));
+        if (ahead > 0 || chained) HIPCHK(hipEventRecord(h->ev_exp[c], h->exp_st));
     }
-    int q = 0;
-    for (hipStream_t s : {h->env_st[0], h->env_st[1], h->exp_st}) { HIPCHK(hipEventRecord(h->ev_join[q], s)); HIPCHK(hipStreamWaitEvent(st, h->ev_join[q], 0)); ++q; }
+    if (last) {
+        int q = 0;
+        for (hipStream_t s : {h->env_st[0], h->env_st[1], h->exp_st}) { HIPCHK(hipEventRecord(h->ev_join[q], s)); HIPCHK(hipStreamWaitEvent(st, h->ev_join[q], 0)); ++q; }
+    }
     HIPCHK(hipGetLastError());
     return GMPE_OK;
 }
@@ -764,6 +786,7 @@ int gmpe_get_tuning(const gmpe_handle* h, gmpe_tuning* t) {
     t->lds_bytes = (int32_t)lds_bytes(h->G, h->A, h->E, h->D, h->c.num_walls);
     t->G_roll = h->G_roll; t->block_roll = h->block_roll;
     t->chunks = h->split ? h->chunks : 0; t->ahead = h->split ? h->ahead : 0;
+    t->xstep = h->split ? h->xstep : 0; t->chunks_x = h->split ? h->chunks_x : 0; t->ahead_x = h->split ? h->ahead_x : 0;
 #ifdef GMPE_DIAG
     t->diag_build = 1;
 #endif
@@ -840,6 +863,18 @@ int gmpe_step_many_launches(gmpe_handle* h, const int32_t* actions_dev, int32_t 
         }
     }
     const size_t stride = (size_t)h->c.num_envs * h->A;
+    if (h->split && h->xstep && !h->timing && num_steps > 1 && out && out->adj && !out->adj_compact) {
+        // open-loop steps on the split path: one chunk pipeline over all the steps (no join between steps)
+        HIPCHK(hipSetDevice(h->device));
+        for (int32_t k = 0; k < num_steps; ++k) {
+            KParams p;
+            fill_params(h, p, h->G);
+            p.o = *out; p.act = actions_dev + (size_t)(k % num_action_sets) * stride; p.mode = MODE_STEP;
+            const int rc = split_pipeline(h, MODE_STEP, p, out->adj, static_cast<hipStream_t>(stream), k == 0, k == num_steps - 1);
+            if (rc) return rc;
+        }
+        return GMPE_OK;
+    }
     for (int32_t k = 0; k < num_steps; ++k) {
         const int rc = launch(h, MODE_STEP, actions_dev + (size_t)(k % num_action_sets) * stride, nullptr, nullptr, out, stream);
         if (rc) return rc;

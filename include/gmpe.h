@@ -293,7 +293,7 @@ int gmpe_masks_from_dones(gmpe_handle* h, const uint8_t* done_dev, float* masks_
 /* What gmpe_create chose for this handle (recorded by bench.py next to every number). Environment variables override the heuristics —
  * GMPE_G / GMPE_BLOCK (step tile shape), GMPE_GROLL (rollout tile shape), GMPE_AP=0 (run-time-size instead of exact-size kernels),
  * GMPE_NT / GMPE_ROLLNT (nontemporal graph stores of step / rollout launches), GMPE_SPEC (wave specialisation), GMPE_SPLIT / GMPE_CHUNKS
- * / GMPE_RAMP / GMPE_AHEAD (split big-E path, its chunk count, quarter + half first chunks, run-ahead bound), GMPE_ROLL (gmpe_step_many as one rollout launch) — none of them changes results
+ * / GMPE_RAMP / GMPE_AHEAD / GMPE_XSTEP (split big-E path, its chunk count, quarter + half first chunks, run-ahead bound, chained steps), GMPE_ROLL (gmpe_step_many as one rollout launch) — none of them changes results
  * (tests/test_gpu_instantiations.py, tests/test_gpu_rollout_kernel.py). */
 typedef struct gmpe_tuning {
     int32_t G;                  /* envs per workgroup (tile)                                               */
@@ -308,7 +308,8 @@ typedef struct gmpe_tuning {
     int32_t diag_build;         /* 1: library built with -DGMPE_DIAG (ablations honoured): never for results */
     int32_t G_roll, block_roll; /* tile shape of the rollout kernel (its own register budget, hence its own residency)  */
     int32_t chunks, ahead;      /* split path: env chunks per step; how many chunks the fused kernel may run ahead of the expansion (0: unbounded) */
-    int32_t reserved[3];
+    int32_t xstep;              /* split path: gmpe_step_many chains the steps' chunk pipelines (no join between open-loop steps)          */
+    int32_t chunks_x, ahead_x;  /* ... with this chunking / run-ahead bound                                                                */
 } gmpe_tuning;
 int gmpe_get_tuning(const gmpe_handle* h, gmpe_tuning* out);
 

@@ -83,7 +83,7 @@ def test_navigation_graph_configs0_three_agents_one_env():
     assert _rollout_vs_oracle(cfg, 30, seed=66) >= 37
 
 
-def _full_size_slice(cfg_kw, n_total, n_slice, steps, act_seed, base=0):
+def _full_size_slice(cfg_kw, n_total, n_slice, steps, act_seed, base=0, many=0):
     """Full-size launch vs an oracle run of n_slice of its envs (the first ones, or those from `base` on), every step; returns the
     last engine outputs."""
     import torch
@@ -114,6 +114,21 @@ def _full_size_slice(cfg_kw, n_total, n_slice, steps, act_seed, base=0):
         np.testing.assert_allclose(eng.get(f)[base:base + n_slice], orc.get(f), rtol=0, atol=1e-9, err_msg=f)
     for f in ("status", "rng_ctr", "current_step", "goal_tracker", "n_agent_coll", "n_obst_coll"):
         np.testing.assert_array_equal(eng.get(f)[base:base + n_slice], orc.get(f), err_msg=f)
+    if many:                                                             # then `many` open-loop steps in ONE gmpe_step_many call, final outputs + state
+        acts = torch.randint(0, cfg.n_actions, (many, n_total, A), generator=g, dtype=torch.int32)
+        o = eng.step_many(acts.to("cuda"), many)
+        for k in range(many):
+            oo = orc.step(acts[k, base:base + n_slice].numpy())
+        np.testing.assert_allclose(_np(o.obs[base:base + n_slice]), oo[0], rtol=0, atol=TOL, err_msg="step_many obs")
+        np.testing.assert_allclose(_np(o.node_obs[base:base + n_slice]), oo[2], rtol=0, atol=TOL, err_msg="step_many node")
+        adj = _np(o.adj[base:base + n_slice])
+        np.testing.assert_allclose(adj, np.broadcast_to(oo[3][:, None], adj.shape), rtol=0, atol=TOL, err_msg="step_many adj")
+        np.testing.assert_allclose(_np(o.reward[base:base + n_slice]), oo[4], rtol=0, atol=TOL, err_msg="step_many rew")
+        np.testing.assert_array_equal(_np(o.done[base:base + n_slice]).astype(bool), oo[5], err_msg="step_many done")
+        for f in ("x", "y", "s2", "s3"):
+            np.testing.assert_allclose(eng.get(f)[base:base + n_slice], orc.get(f), rtol=0, atol=1e-9, err_msg="step_many " + f)
+        for f in ("status", "rng_ctr", "current_step"):
+            np.testing.assert_array_equal(eng.get(f)[base:base + n_slice], orc.get(f), err_msg="step_many " + f)
     eng.check_errors()
     return eng, o, n_resets
 
@@ -159,19 +174,22 @@ def test_full_size_c5_shard_with_oracle_slice(n_envs, ahead):
     """configs[4], one GPU's shard of 8: 2048 envs x 64 agents, E = 128 (8.6 GB of adjacency per step) — the split pipeline; and twice
     that, where the compact-matrix scratch outgrows the Infinity Cache and the fused kernel is held to two chunks ahead of the expansion."""
     eng, o, n_resets = _full_size_slice(dict(scenario_name="navigation_graph", num_agents=64, world_size=12.0, episode_length=5, seed=1234),
-                                        n_envs, 128, 8, 44, base=n_envs - 128 if ahead else 0)   # the big case checks the LAST chunk's envs
+                                        n_envs, 128, 8, 44, base=n_envs - 128 if ahead else 0, many=7)   # the big case checks the LAST chunk's envs; then 7 chained steps
     assert n_resets >= 128
     t = eng.tuning()
     assert t["split"] == 1 and t["ahead"] == ahead and t["chunks"] == 8     # 256-env chunks unbounded, 512-env chunks with the bound
+    assert t["xstep"] == 1 and t["chunks_x"] == n_envs // 512 and t["ahead_x"] == 2   # gmpe_step_many: the steps' pipelines chained
     _graph_invariants(o, 64, 128, 8)
 
 
-@pytest.mark.parametrize("chunks,ahead", [(1, 0), (3, 1), (8, 0), (8, 2)])
-def test_split_pipeline_across_steps_equals_step_loop(monkeypatch, chunks, ahead):
+@pytest.mark.parametrize("chunks,ahead,xstep", [(1, 0, 1), (3, 1, 1), (8, 0, 1), (8, 2, 1), (8, 2, 0), (None, None, 1)])
+def test_split_pipeline_across_steps_equals_step_loop(monkeypatch, chunks, ahead, xstep):
     """gmpe_step_many on the split path (one chunk pipeline per step, any chunk count): same final outputs and state as one
     gmpe_step per step."""
     import torch
-    _knobs(monkeypatch, split=1, chunks=chunks, ahead=ahead)
+    _knobs(monkeypatch, split=1, xstep=xstep)
+    if chunks is not None:
+        _knobs(monkeypatch, chunks=chunks, ahead=ahead)
     cfg = gmpe.make_config(scenario_name="navigation_graph", num_envs=37, num_agents=12, num_obstacles=3, num_walls=4, world_size=5.0,
                            episode_length=6, seed=97)
     e1, e2 = _engine(cfg), _engine(cfg)

@@ -44,6 +44,7 @@ def _draw(k):
         knobs["SPLIT"] = 1
         knobs["CHUNKS"] = int(r.choice([1, 2, 3, 5]))
         knobs["AHEAD"] = int(r.choice([0, 1, 2]))
+        knobs["XSTEP"] = int(r.choice([0, 1, 1]))
     if r.rand() < 0.2:
         knobs["SPEC"] = 0
     if r.rand() < 0.2:

@@ -53,8 +53,6 @@ def main(wl, tag="r02", steps="300", dirtag=None):
         vals[c] = (tot, n)                             # summed over every launch of the step's kernels; n = launches of the k_env instantiation
     wlc = bench.WORKLOADS[wl]
     n_envs = int(os.environ.get("GMPE_PROFILE_ENVS", wlc["envs"]))
-    # split path: k_env launches per step = chunks (+ 2 with the ramped first chunks); GMPE_PROFILE_LPS states it for the profiled handle
-    lps = int(os.environ.get("GMPE_PROFILE_LPS", 10)) if split else 1
     cfg = gmpe.make_config(scenario_name=wlc["scenario_name"], num_envs=n_envs, num_agents=wlc["num_agents"],
                            num_obstacles=wlc["num_obstacles"], num_walls=wlc["num_walls"], world_size=wlc["world_size"],
                            episode_length=wlc["episode_length"])
@@ -62,15 +60,20 @@ def main(wl, tag="r02", steps="300", dirtag=None):
     # env-steps behind the summed counters: a rollout launch runs K steps of every env; a per-step launch one step of every env; a
     # launch of the split pipeline one step of one chunk (N / chunks envs). Every k_env launch of the profiled command is of that kind
     # (tools/profile.sh) except the single reset launch, which is counted like a step.
-    assert vals["WRITE_SIZE"][1] % lps == 0, (vals["WRITE_SIZE"][1], lps)
-    env_steps = vals["WRITE_SIZE"][1] * n_envs * K if roll else vals["WRITE_SIZE"][1] // lps * n_envs
+    # per-step launches: the profiled command (tools/profile.sh) runs 1 reset + 20 warm-up steps + (1 untimed + 3 timed) x K steps + the isolated-launch
+    # pass of min(K, 200) steps; on the split path a step is several chunk launches (and their number differs between gmpe_step and the chained
+    # gmpe_step_many), so the step count, not the launch count, prices the counters
+    steps_total = 21 + 4 * K + min(K, 200)
+    if not roll and not split:
+        assert vals["WRITE_SIZE"][1] == steps_total, (vals["WRITE_SIZE"][1], steps_total)
+    env_steps = vals["WRITE_SIZE"][1] * n_envs * K if roll else steps_total * n_envs
     hbm_total = (vals["WRITE_SIZE"][0] + 2.0 * vals["FETCH_SIZE"][0]) * 1024.0
     per_step_us = (float(kenv["AverageNs"]) / 1e3 / K) if roll else None
     d = {"workload": wl, "envs": n_envs, "dominant_kernel": short(dom["Name"]), "rollout_kernel": roll, "split_path": split,
          "kernels": [{"name": short(r["Name"]), "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3,
                       "max_us": float(r["MaxNs"]) / 1e3, "pct_of_gpu_time": float(r["Percentage"])} for r in fam],
          "avg_launch_us_rocprof": float(dom["AverageNs"]) / 1e3, "steps_per_launch": K if roll else 1, "us_per_step_rocprof": per_step_us,
-         "pmc_k_env_launches": vals["WRITE_SIZE"][1], "k_env_launches_per_step": lps,
+         "pmc_k_env_launches": vals["WRITE_SIZE"][1], "steps_behind_the_counters": None if roll else steps_total,
          "WRITE_SIZE_KB_total": vals["WRITE_SIZE"][0], "FETCH_SIZE_KB_total_raw": vals["FETCH_SIZE"][0],
          "correction": "WRITE_SIZE exact for 16-B/lane streaming stores; FETCH_SIZE doubled (gfx950 reports half of a coalesced "
                        "read stream) per MI355X_MICROARCH.md HBM section; separate --pmc passes",
