@@ -211,7 +211,8 @@ int gmpe_step(gmpe_handle* h, const int32_t* action_idx_dev, const gmpe_outputs*
 int gmpe_step_many(gmpe_handle* h, const int32_t* actions_dev, int32_t num_steps, int32_t num_action_sets,
                    const gmpe_outputs* out, void* stream);
 /* The same steps as ONE KERNEL LAUNCH PER STEP (the closed-loop launch shape, enqueued without host round trips; replays a graph
- * recorded by gmpe_step_many_prepare when there is one). gmpe_step_many falls back to this on the split big-E path. */
+ * recorded by gmpe_step_many_prepare when there is one). gmpe_step_many falls back to this on the split big-E path, where the steps' chunk
+ * pipelines are chained (gmpe_tuning.xstep): the side streams fork before the first step and join the caller's stream after the last one. */
 int gmpe_step_many_launches(gmpe_handle* h, const int32_t* actions_dev, int32_t num_steps, int32_t num_action_sets,
                             const gmpe_outputs* out, void* stream);
 
