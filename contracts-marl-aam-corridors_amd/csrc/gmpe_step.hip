@@ -674,10 +674,11 @@ static void dispatch_env(const gmpe_handle* h, int block, int ap, int fl, hipStr
 //   exp_st:         k_adj_expand(chunk c): scratch -> adj [N,A,E,E]               (HBM-bound fill, 6.5-6.9 TB/s alone)
 // expand(c) waits for k_env(c) through an event, so the expansion of one chunk overlaps the fused kernel of the next; two env
 // streams let one chunk's last, partly filled round of tiles overlap the next chunk's first. Fork from / join into the caller's
-// stream. (Pipelining ACROSS steps as well — expansion of step k under k_env of step k+1, two scratch buffers — was built and
-// measured slower: with both kernels resident all the time the expansion runs at half speed, c4 1563 vs 1252 us; profiles/README.md.)
-// `first` / `last`: gmpe_step_many_launches may chain the pipelines of consecutive steps without joining in between (fork before the first step, join after the
-// last): k_env(step s+1, chunk c) then waits for expand(step s, chunk c) — the reader of the scratch rows it overwrites — instead of for the whole step s.
+// stream. Run-ahead bound (`ahead`): k_env(c) waits for expand(c - ahead) so that the scratch rows the expansion re-reads A times are still in the
+// Infinity Cache (gmpe_create).
+// `first` / `last`: gmpe_step_many_launches chains the pipelines of consecutive open-loop steps without joining in between (fork before the first step,
+// join after the last): k_env(step s+1, chunk c) then waits for expand(step s, chunk c) — the reader of the scratch rows it overwrites — instead of for
+// the whole step s. (A first version with TWO scratch buffers and no bound was slower than joining per step: its live scratch did not fit the cache.)
 static int split_pipeline(gmpe_handle* h, int mode, KParams& p, float* adj_full, hipStream_t st, bool first = true, bool last = true) {
     const bool chained = !(first && last);
     const uint32_t EE = (uint32_t)h->E * h->E;
