@@ -691,10 +691,11 @@ static int split_pipeline(gmpe_handle* h, int mode, KParams& p, float* adj_full,
         for (hipStream_t s : {h->env_st[0], h->env_st[1], h->exp_st}) HIPCHK(hipStreamWaitEvent(s, h->ev_fork, 0));
     }
     // chunk boundaries: equal chunks, except that the first two are a quarter and a half chunk (GMPE_RAMP) so that the expansion stream — the
-    // bottleneck — starts after a quarter of a k_env chunk instead of a whole one
+    // bottleneck — starts after a quarter of a k_env chunk instead of a whole one. Chained steps: only for pipelines of >= 6 chunks per step (us per
+    // step with / without: 1024 envs 729 / 697, 2048: 1375-1431 / 1350, 4096: 2750 / 2790, 8192: 5818 / 6000, 16384: 10941-11219 / 11327-11368)
     int bounds[130]; int nb = 0;
     {
-        const bool ramp = !(getenv("GMPE_RAMP") && !atoi(getenv("GMPE_RAMP"))) && per >= 4 * h->G;   // default on; GMPE_RAMP=0: equal chunks
+        const bool ramp = (getenv("GMPE_RAMP") ? atoi(getenv("GMPE_RAMP")) != 0 : (!chained || C >= 6)) && per >= 4 * h->G;   // GMPE_RAMP=0: equal chunks
         int lo = 0;
         if (ramp) { const int q = (per / 4 + h->G - 1) / h->G * h->G; bounds[nb++] = lo; lo += q; bounds[nb++] = lo; lo += 2 * q; }
         while (lo < N && nb < 129) { bounds[nb++] = lo; lo += per; }
