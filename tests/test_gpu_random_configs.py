@@ -3,6 +3,8 @@ contact family, shared reward — crossed with the performance knobs that select
 run-time sizes, nontemporal stores, split big-E path, wave specialisation): every draw must give the oracle's results, step by step,
 through single launches and then through one rollout launch. The fixed parametrised cases (test_gpu_parity.py,
 test_gpu_instantiations.py) cover the shapes the bench runs; this covers the combinations nobody thought of."""
+import os
+
 import numpy as np
 import pytest
 
@@ -52,7 +54,7 @@ def _draw(k):
     return kw, knobs
 
 
-@pytest.mark.parametrize("k", range(64))
+@pytest.mark.parametrize("k", range(int(os.environ.get("GMPE_SWEEP_DRAWS", "64"))))     # GMPE_SWEEP_DRAWS=1000: the occasional long soak
 def test_random_config_and_knobs_vs_oracle(monkeypatch, k):
     import torch
     kw, knobs = _draw(k)
