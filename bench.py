@@ -268,6 +268,11 @@ def main():
         cl_el, cl_ms = sorted(cl)[1]
         closed = {"ms_per_step": cl_ms / kc, "steps": kc, "launches": kc,
                   "what": "one k_env launch per step (hipGraph of K kernel nodes), same buffers: launch + latency chain + drain per step"}
+        # the same steps with the batch cut into two env ranges, each on its own stream (a runner that double-buffers halves of the batch):
+        # one half's latency chain runs under the other half's store drain
+        eng.step_many_ranges(actions, kc, 2); torch.cuda.synchronize(dev)
+        tr = sorted(timed(lambda kk: eng.step_many_ranges(actions, kk, 2), kc) for _ in range(3))[1]
+        closed["two_ranges_ms_per_step"] = tr[1] / kc
     if mode == "launch-loop" and tuning["split"] and tuning.get("xstep") and not args.no_closed_loop:
         kc = min(K, 40)
         host = lambda kk: [eng.step(actions[(W + k) % n_act_sets]) for k in range(kk)]
@@ -389,6 +394,8 @@ def main():
         if closed is not None:
             closed["frac"] = B * n_envs / (closed["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             closed["env_steps_per_s"] = n_envs / (closed["ms_per_step"] * 1e-3)
+            if "two_ranges_ms_per_step" in closed:
+                closed["two_ranges_frac"] = B * n_envs / (closed["two_ranges_ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             out["closed_loop"] = closed
         if gather is not None:
             out["with_gather"] = gather

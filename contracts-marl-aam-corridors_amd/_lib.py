@@ -15,7 +15,7 @@ SYMBOLS = ["gmpe_abi_version", "gmpe_last_error", "gmpe_obs_dim", "gmpe_node_fea
            "gmpe_field_bytes", "gmpe_get_field", "gmpe_set_field", "gmpe_edges_from_adj", "gmpe_masks_from_dones",
            "gmpe_timing_enable", "gmpe_timing_read", "gmpe_timing_mark", "gmpe_timing_region_ms",
            "gmpe_rollout_steps", "gmpe_get_tuning", "gmpe_step_many_launches", "gmpe_edges_from_adj_compact",
-           "gmpe_set_control_override", "gmpe_field_device_ptr"]
+           "gmpe_set_control_override", "gmpe_field_device_ptr", "gmpe_step_envs", "gmpe_step_many_envs"]
 
 
 class GmpeOutputs(C.Structure):
@@ -63,6 +63,8 @@ def load():
     lib.gmpe_set_rng_tape.argtypes = [P, P, C.c_int64]
     lib.gmpe_reset.argtypes = [P, P, C.POINTER(GmpeOutputs), P]
     lib.gmpe_step.argtypes = [P, P, C.POINTER(GmpeOutputs), P]
+    lib.gmpe_step_envs.argtypes = [P, P, C.POINTER(GmpeOutputs), C.c_int32, C.c_int32, P]
+    lib.gmpe_step_many_envs.argtypes = [P, P, C.c_int32, C.c_int32, C.POINTER(GmpeOutputs), C.c_int32, P]
     lib.gmpe_step_onehot.argtypes = [P, P, C.POINTER(GmpeOutputs), P]
     lib.gmpe_step_many.argtypes = [P, P, C.c_int32, C.c_int32, C.POINTER(GmpeOutputs), P]
     lib.gmpe_step_many_launches.argtypes = [P, P, C.c_int32, C.c_int32, C.POINTER(GmpeOutputs), P]

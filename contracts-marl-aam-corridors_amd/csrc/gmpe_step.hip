@@ -240,6 +240,8 @@ struct gmpe_handle {
     hipStream_t env_st[2] = {nullptr, nullptr}, exp_st = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_chunk;
+    hipStream_t part_st[4] = {nullptr, nullptr, nullptr, nullptr};   // gmpe_step_many_envs: one side stream per env range (created on first use)
+    hipEvent_t part_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_exp;      // expansion of chunk c finished (back-pressure on the k_env streams)
     int ahead = 0;                       // k_env may run at most this many chunks ahead of the expansion (0: unbounded)
     int xstep = 0;                       // gmpe_step_many on the split path: chain the steps' pipelines (no join between steps)
@@ -576,6 +578,8 @@ int gmpe_destroy(gmpe_handle* h) {
         for (hipStream_t s : {h->env_st[0], h->env_st[1], h->exp_st}) if (s) (void)hipStreamDestroy(s);
         for (hipEvent_t e : {h->ev_fork, h->ev_join[0], h->ev_join[1], h->ev_join[2]}) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : h->ev_chunk) if (e) (void)hipEventDestroy(e);
+        for (hipStream_t& s : h->part_st) if (s) { (void)hipStreamDestroy(s); s = nullptr; }
+        for (hipEvent_t& e : h->part_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         for (hipEvent_t e : h->ev_exp) if (e) (void)hipEventDestroy(e);
         h->ev_exp.clear();
         h->ev_chunk.clear();
@@ -727,12 +731,13 @@ static int split_pipeline(gmpe_handle* h, int mode, KParams& p, float* adj_full,
 }
 
 static int launch(gmpe_handle* h, int mode, const int32_t* act, const float* onehot, const uint8_t* mask,
-                  const gmpe_outputs* out, void* stream) {
+                  const gmpe_outputs* out, void* stream, int env_lo = 0, int env_hi = -1) {
     if (!h) return fail(GMPE_ERR_INVALID_ARG, "null handle");
     KParams p;
     fill_params(h, p, h->G);
     if (out) p.o = *out;
     p.act = act; p.onehot = onehot; p.mask = mask; p.mode = mode;
+    if (env_hi >= 0) { p.env_lo = env_lo; p.env_hi = env_hi; }           // gmpe_step_envs: a contiguous env range (pointers stay whole-batch)
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -801,6 +806,37 @@ int gmpe_reset(gmpe_handle* h, const uint8_t* env_mask_dev, const gmpe_outputs* 
 int gmpe_step(gmpe_handle* h, const int32_t* action_idx_dev, const gmpe_outputs* out, void* stream) {
     if (!action_idx_dev) return fail(GMPE_ERR_INVALID_ARG, "gmpe_step: null actions");
     return launch(h, MODE_STEP, action_idx_dev, nullptr, nullptr, out, stream);
+}
+int gmpe_step_envs(gmpe_handle* h, const int32_t* action_idx_dev, const gmpe_outputs* out, int32_t env_lo, int32_t env_hi, void* stream) {
+    if (!h || !action_idx_dev) return fail(GMPE_ERR_INVALID_ARG, "gmpe_step_envs: null argument");
+    if (env_lo < 0 || env_hi > h->c.num_envs || env_lo >= env_hi) return fail(GMPE_ERR_INVALID_ARG, "gmpe_step_envs: bad env range");
+    if (h->split && out && out->adj && !out->adj_compact) return fail(GMPE_ERR_UNSUPPORTED, "gmpe_step_envs: this handle runs the split big-E path (whole-batch steps only)");
+    return launch(h, MODE_STEP, action_idx_dev, nullptr, nullptr, out, stream, env_lo, env_hi);
+}
+int gmpe_step_many_envs(gmpe_handle* h, const int32_t* actions_dev, int32_t num_steps, int32_t num_action_sets, const gmpe_outputs* out,
+                        int32_t parts, void* stream) {
+    if (!h || !actions_dev || num_steps < 0 || num_action_sets < 1) return fail(GMPE_ERR_INVALID_ARG, "gmpe_step_many_envs: bad arguments");
+    if (parts < 1 || parts > 4 || parts > h->c.num_envs) return fail(GMPE_ERR_INVALID_ARG, "gmpe_step_many_envs: 1..4 env ranges");
+    if (h->split && out && out->adj && !out->adj_compact) return fail(GMPE_ERR_UNSUPPORTED, "gmpe_step_many_envs: split big-E path");
+    if (num_steps == 0) return GMPE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int q = 0; q < parts; ++q) if (!h->part_st[q]) HIPCHK(hipStreamCreateWithFlags(&h->part_st[q], hipStreamNonBlocking));
+    for (int q = 0; q <= parts; ++q) if (!h->part_ev[q]) HIPCHK(hipEventCreateWithFlags(&h->part_ev[q], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->part_ev[parts], st));
+    const size_t stride = (size_t)h->c.num_envs * h->A;
+    const int N = h->c.num_envs;
+    for (int q = 0; q < parts; ++q) HIPCHK(hipStreamWaitEvent(h->part_st[q], h->part_ev[parts], 0));
+    for (int32_t k = 0; k < num_steps; ++k)
+        for (int q = 0; q < parts; ++q) {
+            // range q's step k depends only on range q's step k-1 (same side stream): its latency chain runs under the other ranges' store drains
+            const int lo = (int)((long long)N * q / parts / h->G * h->G), hi = q + 1 == parts ? N : (int)((long long)N * (q + 1) / parts / h->G * h->G);
+            if (lo >= hi) continue;
+            const int rc = launch(h, MODE_STEP, actions_dev + (size_t)(k % num_action_sets) * stride, nullptr, nullptr, out, h->part_st[q], lo, hi);
+            if (rc) return rc;
+        }
+    for (int q = 0; q < parts; ++q) { HIPCHK(hipEventRecord(h->part_ev[q], h->part_st[q])); HIPCHK(hipStreamWaitEvent(st, h->part_ev[q], 0)); }
+    return GMPE_OK;
 }
 static bool same_out(const gmpe_outputs& a, const gmpe_outputs& b) {
     return a.obs == b.obs && a.agent_id == b.agent_id && a.node_obs == b.node_obs && a.adj == b.adj && a.reward == b.reward &&

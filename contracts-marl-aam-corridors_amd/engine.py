@@ -100,6 +100,24 @@ class GmpeEngine(object):
         _lib.check(self.lib.gmpe_step(self.h, a.data_ptr(), C.byref(self._o), self._stream()), "gmpe_step")
         return self.out
 
+    def step_envs(self, action_idx, env_lo, env_hi, stream=None):
+        """Step the envs [env_lo, env_hi) only (whole-batch `action_idx` [N,A] and outputs; rows outside the range untouched), on `stream`
+        (a torch.cuda.Stream; default: the current one). Ranges are independent: a runner can double-buffer halves of the batch."""
+        a = action_idx
+        if a.dtype != torch.int32 or not a.is_contiguous() or a.device != self.device or a.numel() != self.N * self.A:
+            raise ValueError("action_idx must be a contiguous int32 device tensor with N*A = %d elements" % (self.N * self.A))
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
+        _lib.check(self.lib.gmpe_step_envs(self.h, a.data_ptr(), C.byref(self._o), int(env_lo), int(env_hi), st), "gmpe_step_envs")
+        return self.out
+
+    def step_many_ranges(self, action_sets, num_steps, parts=2):
+        """num_steps open-loop steps with the batch cut into `parts` env ranges, each on its own side stream (gmpe_step_many_envs)."""
+        a = action_sets
+        self._check_action_sets(a)
+        _lib.check(self.lib.gmpe_step_many_envs(self.h, a.data_ptr(), int(num_steps), int(a.shape[0]), C.byref(self._o), int(parts), self._stream()),
+                   "gmpe_step_many_envs")
+        return self.out
+
     def _check_action_sets(self, a):
         if a.dtype != torch.int32 or not a.is_contiguous() or a.device != self.device or a.dim() != 3:
             raise ValueError("action_sets must be a contiguous int32 device tensor [S, N, A]")

@@ -204,6 +204,16 @@ int gmpe_reset(gmpe_handle* h, const uint8_t* env_mask_dev, const gmpe_outputs* 
  * environment.py:446). */
 int gmpe_step(gmpe_handle* h, const int32_t* action_idx_dev, const gmpe_outputs* out, void* stream);
 
+/* The same step for the envs [env_lo, env_hi) only; `action_idx_dev` and `out` are the WHOLE-batch arrays (rows outside the range are neither
+ * read nor written). Envs are independent (one OS process each in the reference, env_wrappers.py:968-975), so ranges may be stepped on different
+ * streams at different times — e.g. a runner that double-buffers two halves of the batch: while the policy works on one half's observations the
+ * other half steps, and one half's latency chain runs under the other half's store drain. Not on the split big-E path (GMPE_ERR_UNSUPPORTED). */
+int gmpe_step_envs(gmpe_handle* h, const int32_t* action_idx_dev, const gmpe_outputs* out, int32_t env_lo, int32_t env_hi, void* stream);
+/* `num_steps` steps of `parts` (1..4) equal env ranges, each range on a side stream of its own (forked from / joined into `stream` once per call): the launch
+ * shape of a runner that double-buffers ranges of the batch, with the open-loop action source of gmpe_step_many. Same results as gmpe_step_many. */
+int gmpe_step_many_envs(gmpe_handle* h, const int32_t* actions_dev, int32_t num_steps, int32_t num_action_sets, const gmpe_outputs* out,
+                        int32_t parts, void* stream);
+
 /* `num_steps` consecutive steps enqueued by one call (no host round trip between steps; one launch, see gmpe_rollout_steps): step k uses
  * action set k % num_action_sets of `actions_dev` (i32 [num_action_sets, N, A]). Outputs are overwritten
  * by every step (same buffers), exactly as a host loop over gmpe_step would. Used for open-loop rollouts

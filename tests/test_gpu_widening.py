@@ -150,3 +150,39 @@ def test_vec_env_safety_filter_slot_global_features_and_shared_reward_shape():
     assert o[4].shape == (12, 4, 1)                                          # shared reward: [[reward]] * n stacks to [N, A, 1]
     assert np.allclose(o[4], o[4][:, :1])                                    # ... and every agent carries the env's sum
     env.close()
+
+
+@pytest.mark.parametrize("scen,kw", [("navigation_graph", dict(num_obstacles=2, num_walls=4)), (JULY, {}), ("two_phase_graph", {})])
+def test_step_envs_ranges_equal_whole_batch_steps(scen, kw):
+    """gmpe_step_envs / gmpe_step_many_envs: env ranges stepped separately (any order, ranges not aligned to the tile size, own streams) give
+    bit-for-bit what whole-batch steps give — envs are independent (env_wrappers.py:968-975)."""
+    import torch
+    N, A = 53, 6
+    cfg = gmpe.make_config(scenario_name=scen, num_envs=N, num_agents=A, world_size=3.0, episode_length=7, seed=131, **kw)
+    e1, e2, e3 = _engine(cfg), _engine(cfg), _engine(cfg)
+    for e in (e1, e2, e3):
+        e.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    acts = torch.randint(0, cfg.n_actions, (6, N, A), generator=g, device="cuda", dtype=torch.int32)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for k in range(17):
+        o1 = e1.step(acts[k % 6]); e3.step(acts[k % 6])
+        for (lo, hi, st) in ((30, 53, s1), (0, 7, s2), (7, 30, None)):        # out of order, unaligned, three streams
+            o2 = e2.step_envs(acts[k % 6], lo, hi, st)
+        torch.cuda.synchronize()
+        for key in ("obs", "agent_id", "node_obs", "adj", "reward", "done", "info"):
+            assert torch.equal(getattr(o1, key), getattr(o2, key)), (k, key)
+    _compare_state(e1, e2, "ranges")
+    for parts in (1, 2, 3, 4):
+        o3 = e3.step_many_ranges(acts, 4, parts)
+        for k in range(4):
+            o1 = e1.step(acts[k % 6])
+        torch.cuda.synchronize()
+        for key in ("obs", "node_obs", "adj", "reward", "done", "info"):
+            assert torch.equal(getattr(o1, key), getattr(o3, key)), (parts, key)
+        _compare_state(e1, e3, "step_many_ranges parts=%d" % parts)
+    with pytest.raises(gmpe._lib.GmpeError):
+        e2.step_envs(acts[0], 10, 10)
+    for e in (e1, e2, e3):
+        e.check_errors(); e.close()
