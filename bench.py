@@ -61,30 +61,86 @@ PERF_KNOBS = ("GMPE_G", "GMPE_BLOCK", "GMPE_NT", "GMPE_SPEC", "GMPE_SPLIT", "GMP
 DIAG_KNOBS = ("GMPE_ABLATE", "GMPE_LIB")
 
 
-def cpu_baseline(wl, budget_s=12.0):
-    """Time the CPU oracle (single-thread C port of the reference path) on a bounded sample of the
-    same workload. Test infrastructure used as the reported baseline only — never the product path."""
+def host_cpu_budget():
+    """(logical CPUs visible, CPUs this process may use): affinity mask capped by the cgroup CPU quota (cpu.max), which is what the
+    GPU boxes enforce (16 of 128 hardware threads: profiles/r02_notes.md)."""
+    seen = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except Exception:
+        usable = seen
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        pass
+    if quota:
+        usable = max(1, min(usable, int(quota + 0.5)))
+    return seen, usable, quota
+
+
+def _oracle_worker(ol, gmpe, wl, n, base, acts, budget_s, barrier, result, slot):
+    """One host thread: its own oracle handle over its own env shard (global env ids base .. base+n), buffers allocated once; the C call
+    releases the GIL, so W threads are W cores of sequential C — the shape of the reference's W SubprocVecEnv workers (env_wrappers.py:959-1037)."""
+    import ctypes as C
+    import numpy as np
+    cfg = gmpe.make_config(scenario_name=wl["scenario_name"], num_envs=n, num_agents=wl["num_agents"],
+                           num_obstacles=wl["num_obstacles"], num_walls=wl["num_walls"], world_size=wl["world_size"],
+                           episode_length=wl["episode_length"], seed=1234, env_id_base=base)
+    orc = ol.Oracle(cfg)
+    orc.reset()
+    obs, ids, node, adj = orc._bufs()
+    A = cfg.num_agents
+    rew = np.zeros((n, A)); done = np.zeros((n, A), np.uint8); info = np.zeros((n, A, 18)); did = np.zeros(n, np.uint8)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    args = [p(x) for x in (obs, ids, node, adj, rew, done, info, did)]
+    sets = [np.ascontiguousarray(acts[k, base:base + n]) for k in range(acts.shape[0])]
+    barrier.wait()
+    t0 = time.perf_counter(); steps = 0
+    while True:
+        orc.lib.gmpo_step(orc.h, p(sets[steps % len(sets)]), *args, 1); steps += 1
+        if time.perf_counter() - t0 >= budget_s or steps >= 200000:
+            break
+    result[slot] = (n * steps, time.perf_counter() - t0, steps)
+    orc.close()
+
+
+def cpu_baseline(wl, budget_s=10.0, single_s=4.0, envs_per_worker=256):
+    """The CPU oracle (C port of the reference path) timed on a bounded sample of the same workload at HOST scale: W = usable host cores
+    worker threads, each stepping its own env shard (`W = host cores`, aggregate and per-core), after a single-thread
+    leg. Test infrastructure used as the reported baseline only — never the product path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import threading
     import numpy as np
     import gmpe
     import oracle_lib as ol
-    n = 512
-    cfg = gmpe.make_config(scenario_name=wl["scenario_name"], num_envs=n, num_agents=wl["num_agents"],
-                           num_obstacles=wl["num_obstacles"], num_walls=wl["num_walls"],
-                           world_size=wl["world_size"], episode_length=wl["episode_length"], seed=1234)
-    orc = ol.Oracle(cfg)
-    orc.reset()
+    ol.load()
+    seen, W, quota = host_cpu_budget()
+    n = envs_per_worker
     rng = np.random.RandomState(42)
-    acts = rng.randint(0, cfg.n_actions, (64, n, cfg.num_agents)).astype(np.int32)
-    t0 = time.perf_counter(); steps = 0
-    while True:
-        orc.step(acts[steps % 64]); steps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or steps >= 20000:
-            break
-    return {"value": n * steps / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d envs x %d steps of the same workload (%.1f s), single-thread C oracle "
-                      "(oracle/gmpe_oracle.c, fp64 outputs)" % (n, steps, el)}
+    n_act = 25 if wl["scenario_name"] != "navigation_graph" else 5
+    acts = rng.randint(0, n_act, (16, n * W, wl["num_agents"])).astype(np.int32)
+
+    def leg(workers, secs):
+        res = [None] * workers
+        bar = threading.Barrier(workers)
+        th = [threading.Thread(target=_oracle_worker, args=(ol, gmpe, wl, n, q * n, acts, secs, bar, res, q)) for q in range(workers)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        wall = time.perf_counter() - t0
+        return sum(r[0] for r in res) / max(r[1] for r in res), res, wall
+    one, r1, _ = leg(1, single_s)
+    agg, rw, wall = leg(W, budget_s) if W > 1 else (one, r1, 0.0)
+    return {"value": agg, "unit": "env-steps/s", "cores": W, "kind": "port",
+            "per_core": agg / W, "single_thread": one, "host_cores": seen, "cpu_quota": quota,
+            "sample": "%d worker threads x %d envs of the same workload, %d-%d steps each in %.1f s (aggregate over the threads' common window), after a "
+                      "single-thread leg of %d steps (%.1f s); C oracle (oracle/gmpe_oracle.c, fp64 outputs, one handle per thread, the C call releases the GIL)"
+                      % (W, n, min(r[2] for r in rw), max(r[2] for r in rw), budget_s, r1[0][2], single_s)}
 
 
 def numpy_boundary(wl, n_envs, device, steps=30):
@@ -136,7 +192,8 @@ def main():
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the one-launch-per-step side measurement")
     ap.add_argument("--host-loop", action="store_true", help="timed region = gmpe_step called from Python once per step (closed-loop shape)")
     ap.add_argument("--launch-loop", action="store_true", help="timed region = one launch per step enqueued by one C call (hipGraph of K kernel nodes)")
-    ap.add_argument("--slots", type=int, default=1, help="rollout output slots: 1 = every step overwrites the same buffers; T = slot-per-step storage [T, ...]")
+    ap.add_argument("--slots", type=int, default=None, help="rollout output slots (default: 26 = slot-per-step storage [26, ...] as DeviceRolloutBuffer keeps it, "
+                    "so every step's bytes are certainly paid in HBM writes; 1 where 26 steps of outputs do not fit 8 GiB). 1 = every step overwrites the same buffers")
     ap.add_argument("--gather", action="store_true", help="also time step + RCCL gather of the compact rollout slab to rank 0")
     ap.add_argument("--diag", action="store_true", help="allow GMPE_LIB / GMPE_ABLATE (diagnostic A/B runs; recorded in the line, never a result)")
     args = ap.parse_args()
@@ -199,12 +256,17 @@ def main():
     # ---- what one repetition of the timed region launches
     rollout_ok = bool(tuning["roll"]) and not tuning["split"]
     mode = "host-loop" if args.host_loop else ("launch-loop" if (args.launch_loop or not rollout_ok) else "rollout")
+    o = eng.out
+    out_keys = [k for k in StepOutputs.__slots__ if getattr(o, k) is not None]
+    step_bytes = sum(getattr(o, k).numel() * getattr(o, k).element_size() for k in out_keys)
+    # Rollouts write slot-per-step storage [T, ...] by default (what DeviceRolloutBuffer.collect does, onpolicy/utils/graph_buffer.py:168-251): with ONE
+    # slot every step overwrites the same 98 MB (c2), which the 256 MiB Infinity Cache absorbs — the fill pattern alone then "reaches" 8.3 TB/s
+    # (profiles/r02_tilebw.log), so a fraction of the 8 TB/s HBM peak would be priced against a ceiling that does not bind. 26 slots = 2.5 GB per pass.
+    n_slots = args.slots if args.slots is not None else (26 if step_bytes * 26 < (8 << 30) else 1)
     slots = None
-    if mode == "rollout" and args.slots > 1:
-        T = args.slots                                   # slot-per-step storage, as DeviceRolloutBuffer keeps it
-        o = eng.out
-        keys = [k for k in StepOutputs.__slots__ if getattr(o, k) is not None]
-        slots = {k: torch.empty((T,) + tuple(getattr(o, k).shape), dtype=getattr(o, k).dtype, device=dev) for k in keys}
+    if mode == "rollout" and n_slots > 1:
+        slots = {k: torch.empty((n_slots,) + tuple(getattr(o, k).shape), dtype=getattr(o, k).dtype, device=dev) for k in out_keys}
+    dram_certain = step_bytes * (n_slots if mode == "rollout" else 1) > (256 << 20)
     graph_ok = False
     if mode == "launch-loop":
         try:
@@ -218,7 +280,7 @@ def main():
             for k in range(kk):
                 eng.step(actions[(W + k) % n_act_sets])
         elif mode == "rollout" and slots is not None:
-            eng.rollout(actions, kk, slot0=StepOutputs(**{k: v[0] for k, v in slots.items()}), num_slots=args.slots,
+            eng.rollout(actions, kk, slot0=StepOutputs(**{k: v[0] for k, v in slots.items()}), num_slots=n_slots,
                         strides={k: v[0].numel() for k, v in slots.items()})
         elif mode == "rollout":
             eng.rollout(actions, kk)                     # ONE launch: the persistent rollout kernel
@@ -281,24 +343,15 @@ def main():
         cl_el, cl_ms = sorted(cl)[1]
         closed = {"ms_per_step": cl_ms / kc, "steps": kc, "launches": kc,
                   "what": "one gmpe_step per step: the split pipeline forks from and joins into the caller's stream around EVERY step (what a policy-in-the-loop runner gets)"}
-    # ---- side measurement: the same rollout into slot-per-step storage [T, ...] (what DeviceRolloutBuffer.collect does). With ONE slot every
-    # step overwrites the same 98 MB, which the 256 MiB Infinity Cache can absorb; T slots (2.5 GB at c2) cannot be, so this is the figure that
-    # is certainly paid in HBM writes. Only where T slots fit comfortably (c2 / c3-sized outputs).
-    slotted = None
-    if mode == "rollout" and slots is None and not args.no_closed_loop and world == 1:
-        T = 26
-        o = eng.out
-        keys = [k for k in StepOutputs.__slots__ if getattr(o, k) is not None]
-        step_bytes = sum(getattr(o, k).numel() * getattr(o, k).element_size() for k in keys)
-        if step_bytes * T < (8 << 30):
-            st = {k: torch.empty((T,) + tuple(getattr(o, k).shape), dtype=getattr(o, k).dtype, device=dev) for k in keys}
-            roll_T = lambda kk: eng.rollout(actions, kk, slot0=StepOutputs(**{k: v[0] for k, v in st.items()}), num_slots=T,
-                                            strides={k: v[0].numel() for k, v in st.items()})
-            roll_T(K); torch.cuda.synchronize(dev)
-            sl = sorted(timed(roll_T, K) for _ in range(3))[1]
-            slotted = {"slots": T, "ms_per_step": sl[1] / K, "steps": K, "launches": 1, "bytes_written_per_pass_over_the_slots": step_bytes * T,
-                       "what": "ONE launch of the rollout kernel, step k written to slot k % 26 of [26, ...] storage (nontemporal graph stores)"}
-            del st
+    # ---- side measurement: the same rollout overwriting ONE set of output buffers per step (gmpe_step_many's shape). At c2 / c3 sizes the 98 MB stay in
+    # the Infinity Cache, so this is NOT an HBM figure (reported as env-steps/s with its algorithmic GB/s, no fraction of the HBM peak).
+    one_slot = None
+    if mode == "rollout" and slots is not None and not args.no_closed_loop and world == 1:
+        eng.rollout(actions, K); torch.cuda.synchronize(dev)
+        sl = sorted(timed(lambda kk: eng.rollout(actions, kk), K) for _ in range(3))[1]
+        one_slot = {"ms_per_step": sl[1] / K, "steps": K, "launches": 1, "bytes_overwritten_per_step": step_bytes,
+                    "what": "ONE launch of the rollout kernel, every step overwrites the same output buffers (ordinary stores); at this size the "
+                            "writes are absorbed by the 256 MiB Infinity Cache: not an HBM-roofline figure"}
     # separate pass: per-launch events (isolated kernel duration incl. event overhead)
     iso = None
     if mode != "rollout" or not args.no_closed_loop:
@@ -338,7 +391,7 @@ def main():
         avg_ms = region_ms / launches_per_rep
         achieved = B * env_steps_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic, traffic_src = None, None
-        for tag in ("r02", "r01"):
+        for tag in ("r03", "r02", "r01"):
             pj = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (tag, args.workload))
             if os.path.exists(pj) and traffic is None:
                 try:
@@ -354,9 +407,13 @@ def main():
                 fill = json.load(open(fj))["fill_GBps"]["98MB" if B * n_envs < (512 << 20) else "6GB"]
             except Exception:
                 fill = None
-        kernel = {"rollout": "gmpe::k_env<BLOCK, 0, SC, 2> (persistent rollout: K steps per launch)",
-                  "launch-loop": "gmpe::k_env (one launch per step)" + (" + gmpe::k_adj_expand" if tuning["split"] and not args.adj_compact else ""),
-                  "host-loop": "gmpe::k_env (one launch per step, Python loop)"}[mode]
+        sc = {"navigation_graph": 1 if cfg.num_walls > 0 else 0, "nav_metered_one_goal_graph_rotate_tube_july": 2,
+              "nav_graph_metered_single_corridor_rot_inv": 3, "two_phase_graph": 4, "three_phase_graph": 5}[wl["scenario_name"]]
+        ap_roll = tuning["ap"] if (tuning["block_roll"] == 256 and tuning["ap"] == 10) else 0       # gmpe_sc.hip launch_env: what fl == 2 dispatches
+        k_step = "gmpe::k_env<%d, %d, %d, %d>" % (tuning["block"], tuning["ap"], sc, 1 if (tuning["block"] == 256 and tuning["ap"] == 10 and not tuning["nt"] and tuning["spec"]) else 0)
+        kernel = {"rollout": "gmpe::k_env<%d, %d, %d, 2> (persistent rollout: K steps per launch, G = %d envs per tile)" % (tuning["block_roll"], ap_roll, sc, tuning["G_roll"]),
+                  "launch-loop": k_step + " (one launch per step)" + (" + gmpe::k_adj_expand" if tuning["split"] and not args.adj_compact else ""),
+                  "host-loop": k_step + " (one launch per step, Python loop)"}[mode]
         restated = wl["scenario_name"] == "navigation_graph"
         out = {
             "metric": HEADLINE_METRIC if args.workload == "c2" and n_envs == 4096 else "env-steps/sec (whole node), " + wl["name"],
@@ -371,7 +428,8 @@ def main():
                        "episode_length": cfg.episode_length, "adj": "compact [N,E,E]" if args.adj_compact else "materialised [N,A,E,E]",
                        "info": not args.no_info, "state_dtype": "f64", "outputs_dtype": "f32 / i32 / u8",
                        "launch": {"rollout": "ONE launch of the persistent rollout kernel for the K steps (gmpe_rollout_steps), outputs: "
-                                             + ("%d slots [T, ...]" % args.slots if slots is not None else "one slot (every step overwrites the same buffers)"),
+                                             + ("slot-per-step storage, step k -> slot k %% %d of [%d, ...] (%.2f GB per pass over the slots; nontemporal graph stores)" % (n_slots, n_slots, step_bytes * n_slots / 1e9)
+                                                if slots is not None else "one slot (every step overwrites the same %.0f MB)" % (step_bytes / 1e6)),
                                   "launch-loop": ("ONE chunk pipeline over the K open-loop steps from one C call: k_env / k_adj_expand chunk launches of consecutive steps chained "
                                                   "by per-chunk events, fork before the first step and join after the last (gmpe_step_many on the split path)"
                                                   if tuning["split"] and tuning.get("xstep") and not args.adj_compact else
@@ -379,7 +437,10 @@ def main():
                                   "host-loop": "one launch per step, Python loop over gmpe_step"}[mode],
                        "tuning": tuning, "env": env_knobs, "diag": bool(args.diag),
                        "sharding": "env ranges, %d per GPU, no collective in step" % n_envs},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "dram_certain": bool(dram_certain),
+                         "dram_note": ("%.2f GB written per pass over the output storage: past the 256 MiB Infinity Cache, so the stores are paid in HBM writes" % (step_bytes * (n_slots if mode == "rollout" else 1) / 1e9))
+                                      if dram_certain else "the launch overwrites %.0f MB that fit the 256 MiB Infinity Cache: `frac` is algorithmic bytes over the HBM peak, NOT a measured HBM fraction" % (step_bytes / 1e6),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "measured_fill_peak": fill, "frac_of_measured_fill": (achieved / fill) if fill else None,
                          "kernel": kernel, "avg_launch_ms": avg_ms, "launches": launches_per_rep,
@@ -387,10 +448,10 @@ def main():
                          "isolated_launch_ms": iso,
                          "algorithmic_bytes_per_env_step": B, "env_steps_per_launch": env_steps_per_launch},
         }
-        if slotted is not None:
-            slotted["frac"] = B * n_envs / (slotted["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-            slotted["env_steps_per_s"] = n_envs / (slotted["ms_per_step"] * 1e-3)
-            out["rollout_into_slots"] = slotted
+        if one_slot is not None:
+            one_slot["algorithmic_GBps"] = B * n_envs / (one_slot["ms_per_step"] * 1e-3) / 1e9
+            one_slot["env_steps_per_s"] = n_envs / (one_slot["ms_per_step"] * 1e-3)
+            out["one_slot"] = one_slot
         if closed is not None:
             closed["frac"] = B * n_envs / (closed["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             closed["env_steps_per_s"] = n_envs / (closed["ms_per_step"] * 1e-3)
@@ -406,6 +467,7 @@ def main():
                 out["numpy_boundary"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(wl)
+            out["host"] = {"logical_cpus": cb["host_cores"], "cpu_quota": cb["cpu_quota"], "cores_used_by_cpu_baseline": cb["cores"]}
             cj = os.path.join(ROOT, "profiles", "r02_cpu_calibration.json")
             if os.path.exists(cj):
                 try:

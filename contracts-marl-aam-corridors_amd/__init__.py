@@ -16,7 +16,7 @@ def __getattr__(name):
     if name in ("engine", "vec_env", "spaces", "_lib", "sharding", "rollout"):
         import importlib
         return importlib.import_module("." + name, __name__)
-    if name in ("BatchedGraphMPEVecEnv", "GraphMPEEnv", "make_train_env"):
+    if name in ("BatchedGraphMPEVecEnv", "GraphMPEEnv", "make_train_env", "make_eval_env"):
         from . import vec_env
         return getattr(vec_env, name)
     if name == "GmpeEngine":

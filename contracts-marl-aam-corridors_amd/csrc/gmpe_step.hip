@@ -246,6 +246,7 @@ struct gmpe_handle {
     int ahead = 0;                       // k_env may run at most this many chunks ahead of the expansion (0: unbounded)
     int xstep = 0;                       // gmpe_step_many on the split path: chain the steps' pipelines (no join between steps)
     int chunks_x = 1, ahead_x = 0;       // chunking / run-ahead bound of the chained pipeline
+    int ramp = -1;                       // GMPE_RAMP, read once by gmpe_create (-1: the default rule of split_pipeline)
     unsigned long long* stamps = nullptr;
     hipEvent_t region_ev[2] = {nullptr, nullptr};
     int32_t* edge_ws = nullptr;      // [cap_graphs] counts | [cap_graphs] offsets | [cap_graphs/1024+2] chunk sums
@@ -509,6 +510,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
             // pipeline is long at any batch size, so it always uses two rounds of tiles per chunk and the run-ahead bound of 2 (shard: 8 chunks
             // unbounded 1416, 4 chunks D = 2 1383, 3 / 5 / 6 chunks 1409 / 1410 / 1434; D = 1 1982, D = 3 1407).
             h->xstep = getenv("GMPE_XSTEP") ? atoi(getenv("GMPE_XSTEP")) : 1;
+            h->ramp = getenv("GMPE_RAMP") ? (atoi(getenv("GMPE_RAMP")) != 0) : -1;
             h->chunks_x = (int)((tiles_total + 2 * tiles_resident - 1) / (2 * tiles_resident));
             if (h->chunks_x < 2) h->chunks_x = 2;
             if (h->chunks_x > 128) h->chunks_x = 128;
@@ -573,6 +575,7 @@ int gmpe_debug_stamps(gmpe_handle* h, unsigned long long* host_dst, int64_t max_
 #endif
 
 int gmpe_destroy(gmpe_handle* h) {
+    if (h) (void)hipSetDevice(h->device);                             // streams / events / allocations below belong to the handle's device
     if (h) { for (auto& g : h->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); } h->graphs.clear(); if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream); h->cap_stream = nullptr; }
     if (h) {
         for (hipStream_t s : {h->env_st[0], h->env_st[1], h->exp_st}) if (s) (void)hipStreamDestroy(s);
@@ -585,7 +588,6 @@ int gmpe_destroy(gmpe_handle* h) {
         h->ev_chunk.clear();
     }
     if (!h) return GMPE_OK;
-    (void)hipSetDevice(h->device);
     for (void* q : h->allocs) (void)hipFree(q);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     if (h->edge_ws) (void)hipFree(h->edge_ws);
@@ -699,14 +701,18 @@ static int split_pipeline(gmpe_handle* h, int mode, KParams& p, float* adj_full,
     // step with / without: 1024 envs 729 / 697, 2048: 1375-1431 / 1350, 4096: 2750 / 2790, 8192: 5818 / 6000, 16384: 10941-11219 / 11327-11368)
     int bounds[130]; int nb = 0;
     {
-        const bool ramp = (getenv("GMPE_RAMP") ? atoi(getenv("GMPE_RAMP")) != 0 : (!chained || C >= 6)) && per >= 4 * h->G;   // GMPE_RAMP=0: equal chunks
+        const bool ramp = (h->ramp >= 0 ? h->ramp != 0 : (!chained || C >= 6)) && per >= 4 * h->G;   // GMPE_RAMP=0: equal chunks
         int lo = 0;
         if (ramp) { const int q = (per / 4 + h->G - 1) / h->G * h->G; bounds[nb++] = lo; lo += q; bounds[nb++] = lo; lo += 2 * q; }
         while (lo < N && nb < 129) { bounds[nb++] = lo; lo += per; }
         bounds[nb] = N;
         for (int q = 0; q < nb; ++q) if (bounds[q] > N) bounds[q] = N;
+        // every env must be covered by a chunk that has its events: never step a truncated batch silently
+        if (lo < N || nb > (int)h->ev_chunk.size() || nb > (int)h->ev_exp.size())
+            return fail(GMPE_ERR_INVALID_ARG, "split pipeline: " + std::to_string(nb) + " chunks of " + std::to_string(per) + " envs do not fit the " +
+                                              std::to_string(h->ev_chunk.size()) + " chunk events sized by gmpe_create (GMPE_CHUNKS / GMPE_RAMP changed after create?)");
     }
-    for (int c = 0; c < nb && c < (int)h->ev_chunk.size(); ++c) {
+    for (int c = 0; c < nb; ++c) {
         const int lo = bounds[c], hi = bounds[c + 1];
         if (lo >= hi) continue;
         hipStream_t se = h->env_st[c & 1];
@@ -833,7 +839,11 @@ int gmpe_step_many_envs(gmpe_handle* h, const int32_t* actions_dev, int32_t num_
             const int lo = (int)((long long)N * q / parts / h->G * h->G), hi = q + 1 == parts ? N : (int)((long long)N * (q + 1) / parts / h->G * h->G);
             if (lo >= hi) continue;
             const int rc = launch(h, MODE_STEP, actions_dev + (size_t)(k % num_action_sets) * stride, nullptr, nullptr, out, h->part_st[q], lo, hi);
-            if (rc) return rc;
+            if (rc) {                                                   // join what is already enqueued, so the caller's stream stays ordered after it
+                const std::string msg = g_err;
+                for (int j = 0; j < parts; ++j) if (hipEventRecord(h->part_ev[j], h->part_st[j]) == hipSuccess) (void)hipStreamWaitEvent(st, h->part_ev[j], 0);
+                return fail(rc, msg);
+            }
         }
     for (int q = 0; q < parts; ++q) { HIPCHK(hipEventRecord(h->part_ev[q], h->part_st[q])); HIPCHK(hipStreamWaitEvent(st, h->part_ev[q], 0)); }
     return GMPE_OK;

@@ -254,6 +254,8 @@ class GmpeEngine(object):
         adj = adj.reshape(-1, adj.shape[-2], adj.shape[-1]).contiguous()
         B, E = adj.shape[0], adj.shape[-1]
         cap = int(cap if cap is not None else B * E * E)
+        if cap > 2 ** 31 - 1:
+            raise ValueError("edges_from_adj: cap %d does not fit the int32 ABI argument; pass an explicit cap (or use edges_from_adj_compact)" % cap)
         ei = torch.empty((2, cap), dtype=torch.int32, device=self.device)
         ea = torch.empty((cap,), dtype=torch.float32, device=self.device)
         ne = torch.zeros((1,), dtype=torch.int32, device=self.device)
@@ -269,14 +271,25 @@ class GmpeEngine(object):
         compact [N, E, E] adjacency: -> (edge_index [2, M] int64 (or int32), edge_attr [M], M)."""
         adj = adj_compact.reshape(-1, adj_compact.shape[-2], adj_compact.shape[-1]).contiguous()
         N, E = adj.shape[0], adj.shape[-1]
+        ne = torch.zeros((1,), dtype=torch.int32, device=self.device)
+
+        def run(ei, ea, cap):
+            _lib.check(self.lib.gmpe_edges_from_adj_compact(self.h, adj.data_ptr(), N, int(copies), E, float(max_edge_dist), int(inclusive),
+                                                            int(bool(index64)), ei.data_ptr(), ea.data_ptr(), cap, ne.data_ptr(), self._stream()),
+                       "gmpe_edges_from_adj_compact")
+            m = int(ne.item())
+            if m >= 2 ** 31 - 1:
+                raise _lib.GmpeError("edges_from_adj_compact: more than 2^31 - 2 edges (the count saturates, include/gmpe.h): split the batch")
+            return m
+        if cap is None and N * copies * E * E > 2 ** 28:
+            # the worst case (every pair an edge) would be tens of GB at the big configs (c5 shard: 34 GB of int64 ids): size the buffers from a
+            # count-only call (cap = 0 writes nothing) instead
+            dummy = torch.empty((2,), dtype=torch.int64, device=self.device)
+            cap = run(dummy, dummy, 0)
         cap = int(cap if cap is not None else N * copies * E * E)
         ei = torch.empty((2, cap), dtype=torch.int64 if index64 else torch.int32, device=self.device)
         ea = torch.empty((cap,), dtype=torch.float32, device=self.device)
-        ne = torch.zeros((1,), dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.gmpe_edges_from_adj_compact(self.h, adj.data_ptr(), N, int(copies), E, float(max_edge_dist), int(inclusive),
-                                                        int(bool(index64)), ei.data_ptr(), ea.data_ptr(), cap, ne.data_ptr(), self._stream()),
-                   "gmpe_edges_from_adj_compact")
-        m = int(ne.item())
+        m = run(ei, ea, cap)
         return ei[:, :min(m, cap)], ea[:min(m, cap)], m
 
     def masks_from_dones(self, done, masks, active_masks):

@@ -11,8 +11,9 @@ buffer stores (float32 / int32 / bool; onpolicy/utils/graph_buffer.py:84-114).
 import numpy as np
 import torch
 
-from .config import INFO_KEYS, NODE_FEATS, config_from_args
-from .engine import GmpeEngine
+from . import _lib
+from .config import INFO_KEYS, NODE_FEATS, ROT_FAMILY, config_from_args
+from .engine import GmpeEngine, StepOutputs
 from .spaces import Box, Discrete
 
 
@@ -24,18 +25,27 @@ class LazyInfos(object):
     keys every step would dominate the host, so the dicts are created on first access.
     """
 
-    def __init__(self, info_dev, n_envs, n_agents, include_min_time=True, include_phase=False):
+    def __init__(self, info_dev, n_envs, n_agents, include_min_time=True, include_phase=False, owner=None, generation=0, errors=None):
+        """info_dev: the device tensor the step wrote its info rows into. The vec env alternates TWO such tensors (no per-step clone), so
+        the rows stay valid until the step after next; `owner` / `generation` let a late read fail loudly instead of returning a later
+        step's rows. errors: callable run at fetch time (the host synchronises there anyway): raises on sticky device error flags."""
         self._dev = info_dev
         self._host = None
         self._n, self._a = n_envs, n_agents
+        self._owner, self._gen, self._errors = owner, generation, errors
         # (key, column) pairs: 'Min_time_to_goal' only with max_speed (…_july.py:826-828), 'Phase_reached' only in rot_inv (:835)
         self._keys = [(k, j) for j, k in enumerate(INFO_KEYS)
                       if (k != "Min_time_to_goal" or include_min_time) and (k != "Phase_reached" or include_phase)]
 
     def _fetch(self):
         if self._host is None:
+            if self._owner is not None and self._owner._info_gen - self._gen >= 2:
+                raise RuntimeError("infos of step %d read after step %d overwrote their device buffer: read infos (or call .as_array()) "
+                                   "before the step after next" % (self._gen, self._owner._info_gen))
             self._host = self._dev.detach().cpu().numpy().astype(np.float64)
             self._dev = None
+            if self._errors is not None:
+                self._errors()
         return self._host
 
     def __len__(self):
@@ -66,8 +76,12 @@ class BatchedGraphMPEVecEnv(object):
     viewer = None
     metadata = {"render.modes": ["human", "rgb_array"]}
 
-    def __init__(self, all_args, num_envs=None, device=0, env_id_base=0, adj_broadcast_view=True, pinned_host=True, safety_filter=None):
-        """safety_filter: the hook slot of `World.step`'s safety filter (multiagent/core.py:692-736). A callable
+    def __init__(self, all_args, num_envs=None, device=0, env_id_base=0, adj_broadcast_view=True, pinned_host=True, safety_filter=None,
+                 eval_surface=False):
+        """eval_surface: reproduce GraphDummyVecEnv instead (env_wrappers.py:903-956) — what train_mpe.py:36, 61 / eval_mpe.py:36 pick for
+        n_rollout_threads == 1 and GMPERunner.render unpacks (graph_mpe_runner.py:621-622): `step` returns an 8-tuple whose last element is
+        `reset_count` (1 if an env of the batch was auto-reset in this step, else 0; env_wrappers.py:923-936).
+        safety_filter: the hook slot of `World.step`'s safety filter (multiagent/core.py:692-736). A callable
         `f(engine, actions_dev) -> (ctrl [N,A,2] float64 device tensor, use [N,A] uint8 device tensor or None)` called before every
         step; where `use` is set the engine integrates `ctrl` instead of the decoded action. The HJ / CBF filter of the reference
         (safety_filter.py: jax / cvxpy / value-function data) is not built, so `args.use_safety_filter` without a callable raises."""
@@ -75,6 +89,7 @@ class BatchedGraphMPEVecEnv(object):
             raise NotImplementedError("use_safety_filter=True: the HJ/CBF filter is out of scope (DESIGN.md); pass safety_filter=callable "
                                       "to fill the hook slot")
         self._safety_filter = safety_filter
+        self._eval_surface = bool(eval_surface)
         self.cfg = config_from_args(all_args, num_envs=num_envs, env_id_base=env_id_base)
         # The reference's per-agent adj arrays alias ONE E x E matrix per env, so the
         # engine writes that matrix once and the [N,A,E,E] result is a zero-copy broadcast view.
@@ -96,6 +111,12 @@ class BatchedGraphMPEVecEnv(object):
         self.share_agent_id_observation_space = [Box(-np.inf, np.inf, (A * 1,), f32) for _ in range(A)]
         self.waiting = False
         self._pending = None
+        # info rows: two device buffers bound alternately (a LazyInfos keeps a reference to its step's buffer instead of a per-step clone);
+        # sticky device error flags (tape exhausted / placement gave up) travel down with every hand-off and raise GmpeError here
+        o = self.engine.out
+        self._outs = [o, StepOutputs(**{k: (torch.empty_like(o.info) if k == "info" else getattr(o, k)) for k in StepOutputs.__slots__})]
+        self._info_gen = 0
+        self._err_dev = self.engine.state_tensor("error_flags")
         # Host hand-off for the NumPy runner: two alternating sets of pinned staging buffers, filled by asynchronous
         # D2H copies on the engine's stream (arrays returned by step t stay valid until step t+2; the runner copies
         # them into its replay buffer immediately, graph_buffer.py:223-236). pinned_host=False returns fresh arrays.
@@ -106,7 +127,7 @@ class BatchedGraphMPEVecEnv(object):
             o = self.engine.out
             mk = lambda t: torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
             self._host = [dict(obs=mk(o.obs), agent_id=mk(o.agent_id), node_obs=mk(o.node_obs), adj=mk(o.adj),
-                               reward=mk(o.reward), done=mk(o.done)) for _ in range(2)]
+                               reward=mk(o.reward), done=mk(o.done), err=mk(self._err_dev)) for _ in range(2)]
         # Actions go up through pinned staging too: whatever dtype the runner hands over (np.eye(n)[a] is float64, indices are int64) is
         # converted straight INTO the pinned buffer (single-threaded NumPy, see _upload) and uploaded from there.
         dev = self.engine.device
@@ -130,12 +151,22 @@ class BatchedGraphMPEVecEnv(object):
             self._flip ^= 1
             for k in keys:
                 h[k].copy_(getattr(o, k), non_blocking=True)
+            h["err"].copy_(self._err_dev, non_blocking=True)
             torch.cuda.current_stream(self.engine.device).synchronize()
             arrs = [h[k].numpy() for k in keys]
+            err = h["err"].numpy()
         else:
             arrs = [getattr(o, k).detach().cpu().numpy() for k in keys]
+            err = self._err_dev.cpu().numpy()
+        if err.any():
+            self._raise_errors()
         arrs[3] = self._expand_adj(arrs[3])
         return arrs
+
+    def _raise_errors(self):
+        """Sticky per-env error flags of the engine (include/gmpe.h error_flags) -> GmpeError. The reference has no counterpart: its
+        rejection sampler spins forever in a world too small for its agents (…_july.py:462-486), the engine's is bounded."""
+        self.engine.check_errors()
 
     # ------------------------------------------------------------------ GraphSubprocVecEnv surface
     def reset(self, num_current_episode=0):
@@ -156,16 +187,22 @@ class BatchedGraphMPEVecEnv(object):
                 raise ValueError("actions must be [N=%d, A=%d, %d]" % (self.num_envs, self.num_agents, self.cfg.n_actions))
             t = self._upload(a, "onehot")
             self._filter(t)
+            self._next_info()
             self._pending = self.engine.step_onehot(t)
         elif a.ndim == 2:
             if tuple(a.shape) != (self.num_envs, self.num_agents):
                 raise ValueError("actions must be [N=%d, A=%d]" % (self.num_envs, self.num_agents))
             t = self._upload(a, "index")
             self._filter(t)
+            self._next_info()
             self._pending = self.engine.step(t)
         else:
             raise ValueError("actions must be a one-hot [N,A,n_act] or an index [N,A] array")
         self.waiting = True
+
+    def _next_info(self):
+        self._info_gen += 1
+        self.engine.rebind(self._outs[self._info_gen & 1])
 
     def _upload(self, a, kind):
         """Host (NumPy / CPU tensor, any numeric dtype) or device actions -> the engine's device tensor of the right dtype."""
@@ -196,8 +233,12 @@ class BatchedGraphMPEVecEnv(object):
         done = done.astype(bool)
         if self.cfg.collaborative:
             rew = rew[..., None]                       # `reward_n = [[reward]] * self.n` (environment.py:1056-1061) stacks to [N, A, 1]
-        infos = LazyInfos(o.info.clone(), self.num_envs, self.num_agents, include_min_time=self.cfg.max_speed > 0,
-                          include_phase=self.cfg.node_feats == 7)
+        # 'Phase_reached' is an info key of the rot_inv family only (rot_inv.py:835); the July file's info_callback has 17 keys (…_july.py:806-828)
+        infos = LazyInfos(o.info, self.num_envs, self.num_agents, include_min_time=self.cfg.max_speed > 0,
+                          include_phase=self.cfg.scenario in ROT_FAMILY, owner=self, generation=self._info_gen)
+        if self._eval_surface:
+            reset_count = 1 if done.all(axis=1).any() else 0       # GraphDummyVecEnv.step_wait (env_wrappers.py:923-936)
+            return obs, ids, node, adj, rew, done, infos, reset_count
         return obs, ids, node, adj, rew, done, infos
 
     def step(self, actions, num_current_episode=None):
@@ -213,8 +254,11 @@ class BatchedGraphMPEVecEnv(object):
     def close(self):
         if self.closed:
             return
-        self.engine.close()
-        self.closed = True
+        try:
+            self.engine.check_errors()                # last chance to report sticky device errors (synchronises)
+        finally:
+            self.engine.close()
+            self.closed = True
 
     @property
     def unwrapped(self):
@@ -231,13 +275,22 @@ class BatchedGraphMPEVecEnv(object):
 
 
 def make_train_env(all_args, device=0):
-    """Counterpart of onpolicy/scripts/train_mpe.py:21-43 for env_name == 'GraphMPE'."""
+    """Counterpart of onpolicy/scripts/train_mpe.py:21-43 for env_name == 'GraphMPE' (n_rollout_threads == 1 -> the GraphDummyVecEnv shape)."""
     if getattr(all_args, "env_name", "GraphMPE") != "GraphMPE":
         raise NotImplementedError("only the GraphMPE route is built")
-    return BatchedGraphMPEVecEnv(all_args, num_envs=all_args.n_rollout_threads, device=device)
+    return BatchedGraphMPEVecEnv(all_args, num_envs=all_args.n_rollout_threads, device=device, eval_surface=(all_args.n_rollout_threads == 1))
 
 
 def GraphMPEEnv(args, device=0):
     """multiagent/MPE_env.py:56-84 builds ONE env; here that is a batch of one."""
     assert "graph" in args.scenario_name, "Only use graph env for graph scenarios"
     return BatchedGraphMPEVecEnv(args, num_envs=1, device=device)
+
+
+def make_eval_env(all_args, device=0):
+    """Counterpart of onpolicy/scripts/train_mpe.py:46-68 / eval_mpe.py:21-43: n_eval_rollout_threads == 1 selects GraphDummyVecEnv,
+    whose step returns the 8-tuple GMPERunner.render unpacks (graph_mpe_runner.py:621-622)."""
+    if getattr(all_args, "env_name", "GraphMPE") != "GraphMPE":
+        raise NotImplementedError("only the GraphMPE route is built")
+    n = getattr(all_args, "n_eval_rollout_threads", 1)
+    return BatchedGraphMPEVecEnv(all_args, num_envs=n, device=device, eval_surface=(n == 1))

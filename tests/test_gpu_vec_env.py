@@ -145,6 +145,94 @@ def test_returned_arrays_stay_valid_for_one_more_step():
     envs.close(); envs2.close()
 
 
+def test_too_small_world_raises_through_the_drop_in():
+    """Sticky device error flags reach the drop-in user: the bounded rejection sampler gives up in a world too
+    small for its agents (the reference's spins forever, …_july.py:462-486) and reset() / step() / close() raise GmpeError."""
+    from gmpe._lib import GmpeError
+    from gmpe.vec_env import BatchedGraphMPEVecEnv
+    a = _args(world_size=0.5, num_agents=8, num_landmarks=8, n_rollout_threads=8)
+    envs = BatchedGraphMPEVecEnv(a, num_envs=8)
+    with pytest.raises(GmpeError, match="placement gave up"):
+        envs.reset()
+    # through step: the flags are sticky, and an auto-reset inside a step sets them the same way
+    envs2 = BatchedGraphMPEVecEnv(a, num_envs=8)
+    envs2.engine.reset()                                    # engine-level reset: no host check
+    with pytest.raises(GmpeError, match="placement gave up"):
+        envs2.step(np.zeros((8, 8), dtype=np.int64))
+    with pytest.raises(GmpeError):
+        envs2.close()
+    assert envs2.closed
+    envs.closed = True; envs.engine.close()
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_july_global_features_have_the_reference_17_info_keys(pinned):
+    """graph_feat_type='global' makes F = 7 for every scenario, but 'Phase_reached' is a key of the rot_inv family only
+    (rot_inv.py:835); the July info_callback has 17 keys (…_july.py:806-828)."""
+    from gmpe.vec_env import BatchedGraphMPEVecEnv
+    envs = BatchedGraphMPEVecEnv(_args(graph_feat_type="global", n_rollout_threads=6), num_envs=6, pinned_host=pinned)
+    assert envs.node_observation_space[0].shape == (8, 7)
+    envs.reset()
+    out = envs.step(np.zeros((6, 4), dtype=np.int64))
+    keys = set(out[6][0][0].keys())
+    assert len(keys) == 17 and "Phase_reached" not in keys and "Min_time_to_goal" in keys
+    envs.close()
+    rot = BatchedGraphMPEVecEnv(_args(scenario_name="two_phase_graph", graph_feat_type="global", n_rollout_threads=6), num_envs=6)
+    rot.reset()
+    assert len(rot.step(np.zeros((6, 4), dtype=np.int64))[6][0][0]) == 18
+    rot.close()
+
+
+def test_eval_surface_eight_tuple_with_reset_count():
+    """GraphDummyVecEnv.step_wait returns an 8-tuple whose last element is reset_count (env_wrappers.py:920-936), unpacked by
+    GMPERunner.render (graph_mpe_runner.py:621-622); train_mpe.py:36 / eval_mpe.py:36 select it for one rollout thread."""
+    from gmpe.vec_env import make_eval_env, make_train_env
+    a = _args(n_rollout_threads=1, n_eval_rollout_threads=1, episode_length=4)
+    envs = make_eval_env(a)
+    orc = ol.Oracle(envs.cfg)
+    envs.reset(); orc.reset()
+    rng = np.random.RandomState(5)
+    counts = []
+    for step in range(9):
+        actions = rng.randint(0, 25, (1, 4))
+        out = envs.step(np.eye(25)[actions])                # the render loop passes no episode number (graph_mpe_runner.py:621)
+        oo = orc.step(actions)
+        assert len(out) == 8
+        obs, agent_id, node_obs, adj, rewards, dones, infos, reset_count = out
+        np.testing.assert_allclose(obs, oo[0], atol=1e-5); np.testing.assert_array_equal(dones, oo[5])
+        assert reset_count == int(np.all(dones))
+        counts.append(reset_count)
+    assert counts == [0, 0, 0, 1, 0, 0, 0, 1, 0]
+    envs.close()
+    tr = make_train_env(a)                                  # one rollout thread: the reference builds GraphDummyVecEnv here too
+    tr.reset()
+    assert len(tr.step(np.zeros((1, 4), dtype=np.int64))) == 8
+    tr.close()
+    many = make_eval_env(_args(n_eval_rollout_threads=3))
+    many.reset()
+    assert len(many.step(np.zeros((3, 4), dtype=np.int64))) == 7
+    many.close()
+
+
+def test_infos_are_double_buffered_and_stale_reads_fail_loudly():
+    """No per-step device clone of the info rows: two buffers alternate, a LazyInfos read within one more step is exact, a later one raises."""
+    from gmpe.vec_env import BatchedGraphMPEVecEnv
+    envs = BatchedGraphMPEVecEnv(_args(n_rollout_threads=8), num_envs=8)
+    ref = BatchedGraphMPEVecEnv(_args(n_rollout_threads=8), num_envs=8)
+    envs.reset(); ref.reset()
+    a = np.zeros((8, 4), dtype=np.int64)
+    i1 = envs.step(a)[6]; r1 = ref.step(a)[6].as_array().copy()
+    i2 = envs.step(a + 3)[6]; r2 = ref.step(a + 3)[6].as_array().copy()
+    np.testing.assert_array_equal(i1.as_array(), r1)       # read one step late: still this step's rows
+    np.testing.assert_array_equal(i2.as_array(), r2)
+    assert not np.array_equal(r1, r2)
+    i3 = envs.step(a)[6]
+    envs.step(a); envs.step(a)
+    with pytest.raises(RuntimeError, match="overwrote"):
+        i3[0]
+    envs.close(); ref.close()
+
+
 @pytest.mark.parametrize("scen,mode", [("nav_metered_one_goal_graph_rotate_tube_july", "gather"),
                                        ("nav_graph_metered_single_corridor_rot_inv", "gather"),
                                        ("three_phase_graph", "all_gather")])
