@@ -551,17 +551,15 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
             const float kx = (float)l.ex[eb + k], ky = (float)l.ey[eb + k];
             const float kvox = kag ? (float)l.vox[ab + kk] : 0.0f, kvoy = kag ? (float)l.voy[ab + kk] : 0.0f;
             const float kvnx = kag ? (float)l.vnx[ab + kk] : 0.0f, kvny = kag ? (float)l.vny[ab + kk] : 0.0f;
-            const bool knew = kag && l.newf[ab + kk] != 0;
             // goal node feature of an agent: its landmark; in two_phase_graph.py:1405 the corridor exit
             const float gxk = SC == SC_TWO ? (float)l.tube[gg * GMPE_TUBE_STRIDE + T_EXX] : (kag ? (float)l.ex[eb + A + kk] : 0.0f);
             const float gyk = SC == SC_TWO ? (float)l.tube[gg * GMPE_TUBE_STRIDE + T_EXY] : (kag ? (float)l.ey[eb + A + kk] : 0.0f);
             const float typ = kag ? 0.0f : (k < A + L ? 1.0f : 2.0f);
             for (int ei = 0; ei < A; ++ei) {
                 const float apx = (float)l.ex[eb + ei], apy = (float)l.ey[eb + ei];
-                const bool en = l.newf[ab + ei] != 0;
-                const float avx = (float)(en ? l.vnx[ab + ei] : l.vox[ab + ei]), avy = (float)(en ? l.vny[ab + ei] : l.voy[ab + ei]);
+                const float avx = (float)l.vnx[ab + ei], avy = (float)l.vny[ab + ei];   // vn == vo unless the ego reached its goal in this step (section 2)
                 const double cs = l.cn[ab + ei], sn = l.sn[ab + ei];          // ego heading AFTER its own reward
-                const bool post = knew && k <= ei;
+                const bool post = k <= ei;                                    // vn[k] == vo[k] unless k reached its goal in this step
                 const float rvx = (post ? kvnx : kvox) - avx, rvy = (post ? kvny : kvoy) - avy;
                 const float rpx = kx - apx, rpy = ky - apy;
                 double o0, o1, o2, o3, o4, o5;
@@ -588,11 +586,10 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
             const float kx = (float)l.ex[eb + k], ky = (float)l.ey[eb + k];
             const float kvox = kag ? (float)l.vox[ab + kk] : 0.0f, kvoy = kag ? (float)l.voy[ab + kk] : 0.0f;
             const float kvnx = kag ? (float)l.vnx[ab + kk] : 0.0f, kvny = kag ? (float)l.vny[ab + kk] : 0.0f;
-            const bool knew = kag && l.newf[ab + kk] != 0;
             const float gx = kag ? (float)l.ex[eb + A + kk] : kx, gy = kag ? (float)l.ey[eb + A + kk] : ky;
             const float typ = kag ? 0.0f : (k < A + L ? 1.0f : 2.0f);
             for (int ei = 0; ei < A; ++ei) {
-                const bool post = knew && k <= ei;
+                const bool post = k <= ei;                                    // vn[k] == vo[k] unless k reached its goal in this step (section 2)
                 float* dst = base + ((size_t)(gg * A + ei) * E + k) * 7;
                 dst[0] = post ? kvnx : kvox; dst[1] = post ? kvny : kvoy; dst[2] = kx; dst[3] = ky; dst[4] = gx; dst[5] = gy; dst[6] = typ;
             }
@@ -611,9 +608,10 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
             const double kx = l.ex[eb + k], ky = l.ey[eb + k];
             const bool kag = k < A;
             const int kk = kag ? k : 0;
+            // velocities: section 2 leaves vn == vo unless the agent reached its goal in this step, so "the ego's own velocity after its reward" is
+            // vn[ego], and "agent k's velocity as ego sees it" (re-drawn iff k reached the goal and k <= ego) is k <= ego ? vn[k] : vo[k]
             const double kvox = kag ? l.vox[ab + kk] : 0.0, kvoy = kag ? l.voy[ab + kk] : 0.0;
             const double kvnx = kag ? l.vnx[ab + kk] : 0.0, kvny = kag ? l.vny[ab + kk] : 0.0;
-            const bool knew = kag && l.newf[ab + kk] != 0;
             const double gx = kag ? l.ex[eb + A + kk] : kx, gy = kag ? l.ey[eb + A + kk] : ky;
             const float occ = kag ? 0.0f : 1.0f, typ = kag ? 0.0f : (k < A + L ? 1.0f : 2.0f);
             float4* dst = base + (size_t)gg * A * E2 + rem;
@@ -621,12 +619,10 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
                 const bool ok = !AP || ei < A;
                 const int ec = ok ? ei : 0;
                 const double px = l.ex[eb + ec], py = l.ey[eb + ec];
-                const bool en = l.newf[ab + ec] != 0;
-                const double evox = l.vox[ab + ec], evoy = l.voy[ab + ec], evnx = l.vnx[ab + ec], evny = l.vny[ab + ec];
                 float4 val;
                 if (half == 0) {
-                    const double evx = en ? evnx : evox, evy = en ? evny : evoy;
-                    const bool post = knew && k <= ec;
+                    const double evx = l.vnx[ab + ec], evy = l.vny[ab + ec];
+                    const bool post = k <= ec;
                     val = make_float4((float)((post ? kvnx : kvox) - evx), (float)((post ? kvny : kvoy) - evy), (float)(kx - px), (float)(ky - py));
                 } else {
                     val = make_float4((float)(gx - px), (float)(gy - py), occ, typ);
@@ -645,8 +641,10 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
 #endif
 #ifdef GMPE_STAMPS
 #define STAMP(k) do { if (tid == 0 && p.stamps) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define STAMP_T(k, t) do { if (tid == (t) && p.stamps) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define STAMP(k) do { } while (0)
+#define STAMP_T(k, t) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------- the fused kernel
@@ -1281,7 +1279,11 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
                     if (out.agent_id) for (int q = tid; q < Gv * A; q += 64) { const int gg = fdiv(q, A, p.m_A); if (l.flags[gg * 4 + 3]) out.agent_id[(size_t)n0 * A + q] = q - gg * A; }
                 }
             }
-            else stream_graph_fn<BLOCK, AP, SC, FL>(p, out, l, Gv, n0, tid, tid - 64, BLOCK - 64, false, any_mask);
+            else {
+                STAMP_T(9, 64);                                                 // wave 1, right before / after the issue of its share of the graph stores
+                stream_graph_fn<BLOCK, AP, SC, FL>(p, out, l, Gv, n0, tid, tid - 64, BLOCK - 64, false, any_mask);
+                STAMP_T(10, 64);
+            }
             __syncthreads();
         }
         {

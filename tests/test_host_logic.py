@@ -350,3 +350,37 @@ def test_kernels_do_not_spill():
     allowed = lambda n: 16 if re.search(r"ELi10ELi2ELi[01]E", n) else (24 if "Li256ELi10ELi0ELi2E" in n else 0)
     bad = [(n, x) for n, x in zip(names, scratch) if int(x) > allowed(n)]
     assert not bad, bad
+
+
+def test_bench_multi_rank_branch_inits_the_process_group_before_any_gpu_work():
+    """bench.py's multi-rank branch must call init_process_group before anything allocates on / launches to the GPU
+    (engine creation, torch allocations, RNG); pinned on the source order of main()."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    first_init, first_gpu = None, None
+    gpu_calls = {"GmpeEngine", "randint", "empty", "Generator", "synchronize", "reset", "step"}
+    for node in ast.walk(main):
+        if isinstance(node, ast.Call):
+            f = node.func
+            name = f.attr if isinstance(f, ast.Attribute) else getattr(f, "id", "")
+            if name == "init_process_group":
+                first_init = node.lineno if first_init is None else min(first_init, node.lineno)
+            elif name in gpu_calls:
+                first_gpu = node.lineno if first_gpu is None else min(first_gpu, node.lineno)
+    assert first_init is not None and first_gpu is not None and first_init < first_gpu, (first_init, first_gpu)
+    # and the rendezvous is the 127.0.0.1 one the launcher passes (env), never a hostname lookup
+    assert "MASTER_ADDR" not in src or "127.0.0.1" in src
+
+
+def test_bench_cpu_baseline_runs_at_host_scale():
+    """bench.py's cpu_baseline leg: W = usable host cores worker threads over env shards of the C oracle, aggregate,
+    per-core and single-thread figures, core counts stated."""
+    import bench
+    seen, usable, quota = bench.host_cpu_budget()
+    assert 1 <= usable <= seen
+    cb = bench.cpu_baseline(bench.WORKLOADS["c3"], budget_s=1.5, single_s=0.7, envs_per_worker=128)
+    assert cb["kind"] == "port" and cb["cores"] == usable and cb["host_cores"] == seen and cb["unit"] == "env-steps/s"
+    assert cb["value"] > 0 and cb["single_thread"] > 0 and abs(cb["per_core"] * cb["cores"] - cb["value"]) < 1e-6 * cb["value"]
+    if usable >= 4:
+        assert cb["value"] > 1.5 * cb["single_thread"]          # the C call releases the GIL: threads really run in parallel

@@ -62,6 +62,23 @@ __global__ __launch_bounds__(256) void expandX(const v4f* __restrict__ src, v4f*
     const v4f val = src[(size_t)n * nq + m];
     if (NT) __builtin_nontemporal_store(val, dst + (size_t)n * per + j); else dst[(size_t)n * per + j] = val;
 }
+// W: no A-fold re-read of the source — a workgroup owns one env (or 1/P of its matrix), loads its R float4 per thread ONCE into
+// registers and streams the A copies in output order (per copy a contiguous nq/P * 16 B block per workgroup).
+template <int R, bool NT>
+__global__ __launch_bounds__(256) void expandW(const v4f* __restrict__ src, v4f* __restrict__ dst, int N, uint32_t nq, int A, int P) {
+    const uint32_t n = blockIdx.x / P, part = blockIdx.x - n * P, per_part = nq / P;
+    if (n >= (uint32_t)N) return;
+    v4f val[R];
+    const uint32_t m0 = part * per_part + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const uint32_t m = m0 + r * 256u; val[r] = (r * 256u + threadIdx.x < per_part) ? src[(size_t)n * nq + m] : v4f{0, 0, 0, 0}; }
+    v4f* d = dst + (size_t)n * A * nq + m0;
+    for (int a = 0; a < A; ++a) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (r * 256u + threadIdx.x < per_part) { if (NT) __builtin_nontemporal_store(val[r], d + (size_t)a * nq + r * 256u); else d[(size_t)a * nq + r * 256u] = val[r]; }
+    }
+}
 __global__ void fill4(v4f* __restrict__ dst, size_t n4, float v) {
     const v4f x = {v, v, v, v};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) __builtin_nontemporal_store(x, dst + i);
@@ -95,6 +112,18 @@ int main() {
         run("A U=4 nt", [&] { expandA<4, true><<<(total4 + 255) / 256, 256>>>(src, dst, total4, nq, s.A); });
         run("A U=8 nt", [&] { expandA<8, true><<<(total4 + 255) / 256, 256>>>(src, dst, total4, nq, s.A); });
         run("A U=4 plain", [&] { expandA<4, false><<<(total4 + 255) / 256, 256>>>(src, dst, total4, nq, s.A); });
+        for (int P : {1, 2, 4, 8}) {                                      // W: registers hold the matrix part, no re-read
+            char lab[64];
+            const uint32_t per_part = nq / P;
+            if (nq % P) continue;
+            const int R = (int)((per_part + 255) / 256);
+            snprintf(lab, sizeof lab, "W nt P=%d (R=%d)", P, R);
+            const dim3 gW((uint32_t)s.N * P);
+            if (R <= 2) run(lab, [&] { expandW<2, true><<<gW, 256>>>(src, dst, s.N, nq, s.A, P); });
+            else if (R <= 4) run(lab, [&] { expandW<4, true><<<gW, 256>>>(src, dst, s.N, nq, s.A, P); });
+            else if (R <= 8) run(lab, [&] { expandW<8, true><<<gW, 256>>>(src, dst, s.N, nq, s.A, P); });
+            else if (R <= 16) run(lab, [&] { expandW<16, true><<<gW, 256>>>(src, dst, s.N, nq, s.A, P); });
+        }
         for (int gy : {256, 1024}) {
             char lab[64];
             const dim3 gB(((uint32_t)s.A * nq + 255) / 256, gy < s.N ? gy : s.N);

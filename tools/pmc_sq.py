@@ -1,0 +1,29 @@
+"""Summarise gpurun_out/sq{A,B}_<wl>/ (tools/pmc_sq.sh): SQ counters of the dominant k_env launches -> per tile-step figures."""
+import csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+csv.field_size_limit(1 << 30)
+wl = sys.argv[1]; K = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+out = {}
+for p in ("sqA", "sqB"):
+    f = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "%s_%s/**/*counter_collection.csv" % (p, wl)), recursive=True))
+    if not f: continue
+    rows = [r for r in csv.DictReader(open(f[-1])) if "k_env" in r["Kernel_Name"] and ", 2>" in r["Kernel_Name"]]
+    # the K-step rollout launches of the timed region are the longest ones: group by dispatch, keep those with the max WAVE_CYCLES class
+    by = {}
+    for r in rows:
+        by.setdefault(r["Dispatch_Id"], {})[r["Counter_Name"]] = float(r["Counter_Value"])
+    if not by: continue
+    key = "SQ_WAVE_CYCLES" if p == "sqA" else "SQ_INSTS_LDS"
+    big = max(v.get(key, 0) for v in by.values())
+    sel = [v for v in by.values() if v.get(key, 0) > 0.8 * big]
+    for c in sel[0]:
+        out[c] = sum(v[c] for v in sel) / len(sel)
+    out["launches_" + p] = len(sel)
+out["steps_per_launch"] = K
+print(json.dumps(out, indent=1))
+if "SQ_WAVE_CYCLES" in out:
+    wc = out["SQ_WAVE_CYCLES"]
+    print("fractions of wave-cycles: parked (WAIT_ANY) %.3f | issue-stalled (WAIT_INST_ANY) %.3f | active (ACTIVE_INST_ANY) %.3f | of which VALU %.3f" % (
+        out["SQ_WAIT_ANY"] / wc, out["SQ_WAIT_INST_ANY"] / wc, out["SQ_ACTIVE_INST_ANY"] / wc, out["SQ_ACTIVE_INST_VALU"] / wc))
+    print("VALU instructions per tile-step (1024 tiles): %.0f ; per wave-step %.0f" % (out["SQ_INSTS_VALU"] / 1024 / K, out["SQ_INSTS_VALU"] / 4096 / K))
+    print("busy cycles per step (SQ_BUSY_CYCLES / K / XCD-sum?): %.0f" % (out["SQ_BUSY_CYCLES"] / K))

@@ -35,8 +35,11 @@ names = ["S0 load", "S1 F-pass", "S2 dynamics", "S3 dist+static", "S4 phase/draw
 d = np.diff(s[:, :13], axis=1)
 # v3 order in non-reset tiles: S0..S5 (load, F, dyn, dist, phase), then S9 (mask) S10 (adj) -> node -> S13/14/15 sec3 -> S6 -> sec4 -> S7 -> S11 obs -> S12
 def seg(a, b): return np.median(s[:, b] - s[:, a])
-print("v3 timeline (median cycles): load %d | F %d | dyn %d | dist %d | phase %d | mask %d | adj %d | node %d | sec3 %d | sec4 %d | obs-store %d | total %d" % (
-    seg(0,1), seg(1,2), seg(2,3), seg(3,4), seg(4,5), seg(5,9), seg(9,10), seg(10,13), seg(13,6), seg(6,7), seg(7,12), seg(0,12)))
+print("timeline (median cycles): load %d | F %d | dyn %d | dist %d | phase %d | sec3 %d | sec4 %d | tail %d | total %d" % (
+    seg(0,1), seg(1,2), seg(2,3), seg(3,4), seg(4,5), seg(5,6), seg(6,7), seg(7,12), seg(0,12)))
+# slots 9 / 10: wave 1 (thread 64) right before / after its share of the graph stores (the issue of the stores, not their completion)
+print("streaming wave 1: starts %d cycles after the phase barrier, issues its stores for %d cycles; wave 0 finishes sections 3+4 %d cycles after the phase barrier" % (
+    seg(5,9), seg(9,10), seg(5,7)))
 print("blocks", nb, "G/BLOCK env:", os.environ.get("GMPE_G"), os.environ.get("GMPE_BLOCK"))
 tot = (s[:, 12] - s[:, 0])
 print("total cycles/block: median %d  p90 %d" % (np.median(tot), np.percentile(tot, 90)))
