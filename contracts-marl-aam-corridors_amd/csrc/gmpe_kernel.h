@@ -466,6 +466,14 @@ __device__ __forceinline__ void distance_pass(const KParams& p, const Lds& l, in
     }
 }
 
+#define GMPE_NSTAMPS 32
+#ifdef GMPE_STAMPS
+#define STAMP(k) do { if (tid == 0 && p.stamps) p.stamps[(size_t)blockIdx.x * GMPE_NSTAMPS + (k)] = __builtin_readcyclecounter(); } while (0)
+#define STAMP_T(k, t) do { if (tid == (t) && p.stamps) p.stamps[(size_t)blockIdx.x * GMPE_NSTAMPS + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#define STAMP_T(k, t) do { } while (0)
+#endif
 #define SWEEP(var, n) _Pragma("unroll") for (int var = 0; var < (AP ? AP : (n)); ++var)
 // Graph outputs of a tile: optional adjacency mask pass (block-wide, with its barrier), then the adj and node_obs
 // stores executed by threads t0, t0+nthr, ... (all BLOCK threads, or only the streaming waves of a specialised tile).
@@ -537,6 +545,7 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
         }
     }
     
+    STAMP_T(16, 64); STAMP_T(19, 192);                                     // diagnostic build: adjacency part issued (waves 1 / 3)
     if (sc_rotfam(SC) && o.node_obs && !(abl & 2) && p.c.graph_feat_type != 1) {
         // rot_inv node row (…rot_inv.py:1690-1766): 7 float32 = [rel_vel, rel_pos, rel_goal (all rotated by the ego heading), type].
         // Positions / velocities are rounded to float32 FIRST, differenced in float32, rotated in float64, rounded again.
@@ -638,13 +647,6 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
 #endif
 #ifndef GMPE_MIN_WAVES_NOWALLS
 #define GMPE_MIN_WAVES_NOWALLS 1
-#endif
-#ifdef GMPE_STAMPS
-#define STAMP(k) do { if (tid == 0 && p.stamps) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
-#define STAMP_T(k, t) do { if (tid == (t) && p.stamps) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define STAMP(k) do { } while (0)
-#define STAMP_T(k, t) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------- the fused kernel
@@ -1267,7 +1269,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
                     }
                 }
                 STAMP(7);
-                if (spec && !ROLL) {                                        // wave-local: the rows were written by this wave's own lanes
+                if (spec && !ROLL) {       // wave-local: the rows were written by this wave's own lanes
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1280,9 +1282,9 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
                 }
             }
             else {
-                STAMP_T(9, 64);                                                 // wave 1, right before / after the issue of its share of the graph stores
+                STAMP_T(9, 64); STAMP_T(17, 192);                                // waves 1 / 3, right before / after the issue of their share of the graph stores
                 stream_graph_fn<BLOCK, AP, SC, FL>(p, out, l, Gv, n0, tid, tid - 64, BLOCK - 64, false, any_mask);
-                STAMP_T(10, 64);
+                STAMP_T(10, 64); STAMP_T(18, 192);
             }
             __syncthreads();
         }

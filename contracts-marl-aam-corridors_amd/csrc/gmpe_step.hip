@@ -556,7 +556,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     {
         const size_t grid = (N + G - 1) / G;
         void* q = nullptr;
-        if (hipMalloc(&q, grid * 16 * 8) == hipSuccess) { (void)hipMemset(q, 0, grid * 16 * 8); h->allocs.push_back(q); h->stamps = static_cast<unsigned long long*>(q); }
+        if (hipMalloc(&q, grid * GMPE_NSTAMPS * 8) == hipSuccess) { (void)hipMemset(q, 0, grid * GMPE_NSTAMPS * 8); h->allocs.push_back(q); h->stamps = static_cast<unsigned long long*>(q); }
     }
 #endif
     *out = h;
@@ -569,7 +569,7 @@ int gmpe_debug_stamps(gmpe_handle* h, unsigned long long* host_dst, int64_t max_
     const int64_t grid = (h->c.num_envs + h->G - 1) / h->G;
     const int64_t nb = grid < max_blocks ? grid : max_blocks;
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(host_dst, h->stamps, (size_t)nb * 16 * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(host_dst, h->stamps, (size_t)nb * GMPE_NSTAMPS * 8, hipMemcpyDeviceToHost));
     return (int)nb;
 }
 #endif

@@ -2,7 +2,10 @@
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csv.field_size_limit(1 << 30)
+sys.path.insert(0, ROOT)
+import bench
 wl = sys.argv[1]; K = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+N = bench.WORKLOADS[wl]["envs"]
 out = {}
 for p in ("sqA", "sqB"):
     f = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "%s_%s/**/*counter_collection.csv" % (p, wl)), recursive=True))
@@ -25,5 +28,9 @@ if "SQ_WAVE_CYCLES" in out:
     wc = out["SQ_WAVE_CYCLES"]
     print("fractions of wave-cycles: parked (WAIT_ANY) %.3f | issue-stalled (WAIT_INST_ANY) %.3f | active (ACTIVE_INST_ANY) %.3f | of which VALU %.3f" % (
         out["SQ_WAIT_ANY"] / wc, out["SQ_WAIT_INST_ANY"] / wc, out["SQ_ACTIVE_INST_ANY"] / wc, out["SQ_ACTIVE_INST_VALU"] / wc))
-    print("VALU instructions per tile-step (1024 tiles): %.0f ; per wave-step %.0f" % (out["SQ_INSTS_VALU"] / 1024 / K, out["SQ_INSTS_VALU"] / 4096 / K))
-    print("busy cycles per step (SQ_BUSY_CYCLES / K / XCD-sum?): %.0f" % (out["SQ_BUSY_CYCLES"] / K))
+    print("VALU wave-instructions per env-step: %.0f (%d envs x %d steps per launch); quad-cycles per VALU instruction %.2f" % (
+        out["SQ_INSTS_VALU"] / N / K, N, K, out["SQ_ACTIVE_INST_VALU"] / out["SQ_INSTS_VALU"]))
+    # SQ_BUSY_CYCLES is summed over the 32 shader engines (8 XCDs x 4): cycles of the launch = SQ_BUSY_CYCLES / 32
+    cyc = out["SQ_BUSY_CYCLES"] / 32
+    print("launch: %.0f shader cycles (%.0f per step); VALU pipe busy = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x launch cycles) = %.3f" % (
+        cyc, cyc / K, out["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cyc))

@@ -27,7 +27,7 @@ else:
 torch.cuda.synchronize()
 lib = _lib.load()
 lib.gmpe_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
-buf = np.zeros((8192, 16), dtype=np.uint64)
+buf = np.zeros((8192, 32), dtype=np.uint64)
 nb = lib.gmpe_debug_stamps(eng.h, buf.ctypes.data_as(C.c_void_p), 8192)
 s = buf[:nb].astype(np.int64)
 s = s[s[:, 0] > 0]                                      # split path: every chunk launch stamps blocks 0..tiles-1 of ITS grid; the last chunk's rows survive
@@ -38,8 +38,8 @@ def seg(a, b): return np.median(s[:, b] - s[:, a])
 print("timeline (median cycles): load %d | F %d | dyn %d | dist %d | phase %d | sec3 %d | sec4 %d | tail %d | total %d" % (
     seg(0,1), seg(1,2), seg(2,3), seg(3,4), seg(4,5), seg(5,6), seg(6,7), seg(7,12), seg(0,12)))
 # slots 9 / 10: wave 1 (thread 64) right before / after its share of the graph stores (the issue of the stores, not their completion)
-print("streaming wave 1: starts %d cycles after the phase barrier, issues its stores for %d cycles; wave 0 finishes sections 3+4 %d cycles after the phase barrier" % (
-    seg(5,9), seg(9,10), seg(5,7)))
+print("streaming wave 1: starts %d cycles after the phase barrier, issues its stores for %d cycles (adjacency %d | node rows %d); wave 3: %d (adjacency %d | node rows %d); "
+      "wave 0 finishes sections 3+4 %d cycles after the phase barrier" % (seg(5,9), seg(9,10), seg(9,16), seg(16,10), seg(17,18), seg(17,19), seg(19,18), seg(5,7)))
 print("blocks", nb, "G/BLOCK env:", os.environ.get("GMPE_G"), os.environ.get("GMPE_BLOCK"))
 tot = (s[:, 12] - s[:, 0])
 print("total cycles/block: median %d  p90 %d" % (np.median(tot), np.percentile(tot, 90)))
