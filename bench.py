@@ -262,10 +262,16 @@ def main():
     o = eng.out
     out_keys = [k for k in StepOutputs.__slots__ if getattr(o, k) is not None]
     step_bytes = sum(getattr(o, k).numel() * getattr(o, k).element_size() for k in out_keys)
-    # Rollouts write slot-per-step storage [T, ...] by default (what DeviceRolloutBuffer.collect does, onpolicy/utils/graph_buffer.py:168-251): with ONE
-    # slot every step overwrites the same 98 MB (c2), which the 256 MiB Infinity Cache absorbs — the fill pattern alone then "reaches" 8.3 TB/s
-    # (profiles/r02_tilebw.log), so a fraction of the 8 TB/s HBM peak would be priced against a ceiling that does not bind. 26 slots = 2.5 GB per pass.
-    n_slots = args.slots if args.slots is not None else (26 if step_bytes * 26 < (8 << 30) else 1)
+    # Rollouts write slot-per-step storage [T, ...] by default (what DeviceRolloutBuffer.collect does, onpolicy/utils/graph_buffer.py:168-251: T = episode
+    # length + 1 = 26). With ONE slot every step overwrites the same buffers: at c2 / c3 sizes (98 MB) the 256 MiB Infinity Cache absorbs that — the fill
+    # pattern alone then "reaches" 8.3 TB/s (profiles/r02_tilebw.log), so a fraction of the 8 TB/s HBM peak would be priced against a ceiling that does
+    # not bind; 26 slots are 2.5 GB per pass. At c4 (6 GB per step: DRAM traffic either way) the persistent tiles of a one-slot rollout rewrite the same
+    # 0.7 MB block every step and run 29 % slower than into 26 slots (1122 vs 870 us per step, profiles/r03_notes.md) — both are reported.
+    free_b = torch.cuda.mem_get_info(dev)[0]
+    budget = min(int(free_b * 0.75), 200 << 30)
+    n_slots = args.slots if args.slots is not None else (26 if step_bytes * 26 <= budget else int(max(1, budget // max(1, step_bytes))))
+    if n_slots < 4:
+        n_slots = 1
     slots = None
     if mode == "rollout" and n_slots > 1:
         slots = {k: torch.empty((n_slots,) + tuple(getattr(o, k).shape), dtype=getattr(o, k).dtype, device=dev) for k in out_keys}
@@ -352,9 +358,12 @@ def main():
     if mode == "rollout" and slots is not None and not args.no_closed_loop and world == 1:
         eng.rollout(actions, K); torch.cuda.synchronize(dev)
         sl = sorted(timed(lambda kk: eng.rollout(actions, kk), K) for _ in range(3))[1]
-        one_slot = {"ms_per_step": sl[1] / K, "steps": K, "launches": 1, "bytes_overwritten_per_step": step_bytes,
-                    "what": "ONE launch of the rollout kernel, every step overwrites the same output buffers (ordinary stores); at this size the "
-                            "writes are absorbed by the 256 MiB Infinity Cache: not an HBM-roofline figure"}
+        cache_resident = step_bytes <= (256 << 20)
+        one_slot = {"ms_per_step": sl[1] / K, "steps": K, "launches": 1, "bytes_overwritten_per_step": step_bytes, "cache_resident": cache_resident,
+                    "what": ("ONE launch of the rollout kernel, every step overwrites the same output buffers (ordinary stores); at this size the "
+                             "writes are absorbed by the 256 MiB Infinity Cache: not an HBM-roofline figure") if cache_resident else
+                            ("ONE launch of the rollout kernel, every step overwrites the same output buffers (nontemporal stores; far past the "
+                             "Infinity Cache, so this is HBM traffic too): each persistent tile rewrites its own block every step")}
     # separate pass: per-launch events (isolated kernel duration incl. event overhead)
     iso = None
     if mode != "rollout" or not args.no_closed_loop:
@@ -453,6 +462,8 @@ def main():
         }
         if one_slot is not None:
             one_slot["algorithmic_GBps"] = B * n_envs / (one_slot["ms_per_step"] * 1e-3) / 1e9
+            if not one_slot["cache_resident"]:
+                one_slot["frac"] = one_slot["algorithmic_GBps"] / HBM_PEAK_GBS
             one_slot["env_steps_per_s"] = n_envs / (one_slot["ms_per_step"] * 1e-3)
             out["one_slot"] = one_slot
         if closed is not None:

@@ -267,6 +267,28 @@ __device__ __forceinline__ void write_obs_rot(const KParams& p, const Lds& l, in
     } else o[12] = (float)phase;
 }
 
+// Draw window of a resetting env: its A agent lanes evaluate A consecutive draws of the env's stream at once — one Philox evaluation (or one tape load) per
+// lane — into the env's LDS slots, instead of every lane evaluating every draw of the sequential placement loop (the lanes of an env run that loop in lock
+// step, so they all need the same draw at the same time). win_draw(k) serves draw k and refills the window when k runs past it; values, order and the sticky
+// tape-exhausted flag are exactly draw_at's (a draw past the tape only counts when it is consumed).
+__device__ __forceinline__ double win_draw(const KParams& p, double* buf, int64_t& base, int W, int n, int i, int64_t k, int& err) {
+    if (k >= base + W) {                                                     // env-uniform (k and base are)
+        base = k;
+        const int64_t kk = k + i;
+        double val;
+        if (p.s.tape) val = kk < p.s.tape_len ? p.s.tape[(size_t)n * p.s.tape_len + kk] : __builtin_nan("");
+        else val = philox_uniform(p.c.seed, (uint32_t)(p.c.env_id_base + n), (uint64_t)kk);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");               // earlier reads of the old window are done
+        buf[i] = val;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // LDS operations of one wave execute in order
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    double v = buf[(int)(k - base)];
+    if (v != v) { err |= 1; v = 0.5; }                                       // tape exhausted (draw_at's rule)
+    return v;
+}
+
 // Reset of the envs of a tile by wave 0 (reset_world: …_july.py:339-420, 440-515, 518-613, custom_scenarios/utils.py:165-193;
 // navigation_graph: DESIGN.md). The reference places entities one after another with rejection sampling — inherently sequential
 // in the entity index, but each attempt's collision test against the already placed entities is not: every agent lane of the env
@@ -283,15 +305,17 @@ __device__ __forceinline__ void reset_world_coop(const KParams& p, const Lds& l,
     const double ws = c.world_size, size = c.entity_size;
     const int A = p.A, L = p.L, O = p.O;
     const int o0 = A + L;
+    int64_t wbase = -(int64_t)A - 1;                                        // empty window; slots = the env's spacing-error row (consumed before a reset)
+#define WDRAW(k) win_draw(p, l.serr, wbase, A, n, i, (k), err)
     if (sc_kinematic(SC)) {
         double entx = 0, enty = 0, exx = 0, exy = 0, sa = 0, ca = 1;
         if (mine) {
-            (void)draw_at(c, p.s, n, ctr++, err);                              // wall_length draw, unused (:368)
+            (void)WDRAW(ctr++);                              // wall_length draw, unused (:368)
             const double a = 3 * size * 2.5, b = ws * 0.15;
             const double width = a > b ? a : b;
-            const double angle = -M_PI / 2 + (M_PI / 2 - (-M_PI / 2)) * draw_at(c, p.s, n, ctr++, err);
+            const double angle = -M_PI / 2 + (M_PI / 2 - (-M_PI / 2)) * WDRAW(ctr++);
             double tl = ws * 0.8;
-            if (sc_phasefam(SC)) tl += -ws * 0.3 + (ws * 0.1 - (-ws * 0.3)) * draw_at(c, p.s, n, ctr++, err);   // two_phase_graph.py:506
+            if (sc_phasefam(SC)) tl += -ws * 0.3 + (ws * 0.1 - (-ws * 0.3)) * WDRAW(ctr++);   // two_phase_graph.py:506
             ca = cos(angle); sa = sin(angle);
             const double be = tl / 4, bx = -tl / 4;
             entx = ca * 0 + sa * be; enty = -sa * 0 + ca * be;
@@ -311,7 +335,7 @@ __device__ __forceinline__ void reset_world_coop(const KParams& p, const Lds& l,
         double mx = 0, my = 0;                                              // agent i's accepted position (this lane owns agent i)
         while (__ballot(mine && k < A)) {
             if (mine && k < A) {
-                const double u0 = draw_at(c, p.s, n, ctr, err), u1 = draw_at(c, p.s, n, ctr + 1, err);
+                const double u0 = WDRAW(ctr), u1 = WDRAW(ctr + 1);
                 ctr += 2;
                 constexpr bool rot = sc_rotfam(SC);             // rot_inv.py:463, 469
                 const double jf = rot ? 0.3 : 0.2;
@@ -324,7 +348,7 @@ __device__ __forceinline__ void reset_world_coop(const KParams& p, const Lds& l,
                 const bool bad = (__ballot(bad_i) & emask) != 0ull;
                 if (bad && ++tries < GMPE_MAX_TRIES) continue;
                 if (bad) err |= 2;
-                const double th = 0.0 + (2 * M_PI - 0.0) * draw_at(c, p.s, n, ctr++, err);
+                const double th = 0.0 + (2 * M_PI - 0.0) * WDRAW(ctr++);
                 if (i == k) { mx = px; my = py; l.ex[k] = px; l.ey[k] = py; l.n2[k] = th; l.n3[k] = c.v_min; }
                 ++k; tries = 0;
             }
@@ -340,8 +364,8 @@ __device__ __forceinline__ void reset_world_coop(const KParams& p, const Lds& l,
         // obstacles: >= 2*(size+size) apart; lane i owns obstacles i, i+A, ...
         while (__ballot(mine && k < O)) {
             if (mine && k < O) {
-                const double px = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr, err));
-                const double py = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr + 1, err));
+                const double px = 0.8 * (lo + (hi - lo) * WDRAW(ctr));
+                const double py = 0.8 * (lo + (hi - lo) * WDRAW(ctr + 1));
                 ctr += 2;
                 bool bad_i = false;
                 for (int q = i; q < k; q += A) bad_i = bad_i || norm2(l.ex[o0 + q] - px, l.ey[o0 + q] - py) < 2.0 * (size + size);
@@ -357,8 +381,8 @@ __device__ __forceinline__ void reset_world_coop(const KParams& p, const Lds& l,
         double mx = 0, my = 0;
         while (__ballot(mine && k < A)) {
             if (mine && k < A) {
-                const double px = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr, err));
-                const double py = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr + 1, err));
+                const double px = 0.8 * (lo + (hi - lo) * WDRAW(ctr));
+                const double py = 0.8 * (lo + (hi - lo) * WDRAW(ctr + 1));
                 ctr += 2;
                 bool bad_i = wall_band_hit(p, px, py, size);
                 for (int o = i; o < O; o += A) bad_i = bad_i || norm2(l.ex[o0 + o] - px, l.ey[o0 + o] - py) < 2.0 * (size + size);
@@ -374,8 +398,8 @@ __device__ __forceinline__ void reset_world_coop(const KParams& p, const Lds& l,
         k = 0; tries = 0;
         while (__ballot(mine && k < L)) {
             if (mine && k < L) {
-                const double px = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr, err));
-                const double py = 0.8 * (lo + (hi - lo) * draw_at(c, p.s, n, ctr + 1, err));
+                const double px = 0.8 * (lo + (hi - lo) * WDRAW(ctr));
+                const double py = 0.8 * (lo + (hi - lo) * WDRAW(ctr + 1));
                 ctr += 2;
                 bool bad_i = wall_band_hit(p, px, py, size);
                 for (int o = i; o < O; o += A) bad_i = bad_i || norm2(l.ex[o0 + o] - px, l.ey[o0 + o] - py) < 2.0 * (size + size);
@@ -397,6 +421,7 @@ __device__ __forceinline__ void reset_world_coop(const KParams& p, const Lds& l,
         p.s.landmarks[((size_t)n * L + q) * 2 + 1] = l.ey[A + q];
     }
 }
+#undef WDRAW
 
 
 // Post-move distance pass for every env of the tile (World.calculate_distances, core.py:600-624:

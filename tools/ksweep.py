@@ -22,7 +22,7 @@ def main():
     out_path = sys.argv[2] if len(sys.argv) > 2 else None
     Ks = [int(x) for x in os.environ.get("KSWEEP_K", "5,20,100,1000").split(",")]
     wl = bench.WORKLOADS[key]
-    n = wl["envs"]
+    n = int(os.environ.get("KSWEEP_ENVS", wl["envs"]))
     cfg = gmpe.make_config(scenario_name=wl["scenario_name"], num_envs=n, num_agents=wl["num_agents"], num_obstacles=wl["num_obstacles"],
                            num_walls=wl["num_walls"], world_size=wl["world_size"], episode_length=wl["episode_length"], seed=1234)
     dev = torch.device("cuda", 0)
@@ -33,14 +33,17 @@ def main():
     eng.reset()
     for k in range(25):
         eng.step(actions[k])
-    T = 26
+    T = int(os.environ.get("KSWEEP_SLOTS", "26"))
     o = eng.out
     keys = [k for k in StepOutputs.__slots__ if getattr(o, k) is not None]
     st = {k: torch.empty((T,) + tuple(getattr(o, k).shape), dtype=getattr(o, k).dtype, device=dev) for k in keys}
     slot0 = StepOutputs(**{k: v[0] for k, v in st.items()})
     strides = {k: v[0].numel() for k, v in st.items()}
+    if os.environ.get("KSWEEP_STRIDE0") == "1":                # diagnostic: T slots that all alias slot 0 (same kernel path, no address diversity)
+        strides = {k: 0 for k in strides}
+    closed = os.environ.get("KSWEEP_CLOSED", "1") == "1"
 
-    def region(fn, K, reps=7):
+    def region(fn, K, reps=int(os.environ.get("KSWEEP_REPS", "7"))):
         fn(K); torch.cuda.synchronize(dev)
         ms = []
         for _ in range(reps):
@@ -54,14 +57,17 @@ def main():
     res = {"workload": key, "envs": n, "algorithmic_bytes_per_env_step": B, "peak_GBps": bench.HBM_PEAK_GBS, "tuning": eng.tuning(), "points": []}
     for K in Ks:
         shapes = {
-            "slots26": lambda kk: eng.rollout(actions, kk, slot0=slot0, num_slots=T, strides=strides),
+            "slots%d" % T: lambda kk: eng.rollout(actions, kk, slot0=slot0, num_slots=T, strides=strides),
             "one_slot": lambda kk: eng.rollout(actions, kk),
         }
-        try:
-            eng.step_many_prepare(actions, K)
-        except Exception:
-            pass
-        shapes["closed_loop"] = lambda kk: eng.step_many_loop(actions, kk)
+        if closed:
+            try:
+                eng.step_many_prepare(actions, K)
+            except Exception:
+                pass
+            shapes["closed_loop"] = lambda kk: eng.step_many_loop(actions, kk)
+        if eng.tuning()["split"]:
+            shapes = {"split_pipeline_chained": lambda kk: eng.step_many(actions, kk)}
         for name, fn in shapes.items():
             med, all_ms = region(fn, K)
             us = med / K * 1e3
