@@ -1319,7 +1319,9 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
                 const bool mine = ag && v.flags[0];
                 if (tid < 64) {                                                   // wave 0 holds every agent lane: placement is a wave-cooperative loop
                     int64_t ctr = ctr0 + ((mine && step) ? v.flags[1] : 0);      // this step's heading re-draws come first
+                    STAMP(20);
                     reset_world_coop<SC>(p, v, n, i, mine, emask, ctr, err);
+                    STAMP(21);
                     if (mine && i == 0) {
                         if (ROLL) reinterpret_cast<long long*>(l.cntd + (size_t)G * A * 2 + G)[g] = ctr;
                         p.s.rng_ctr[n] = ctr;
@@ -1349,9 +1351,11 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
                     p.s.goal_min_time[na] = gmt;
                     ph1 = ph;
                 }
+                STAMP(22);
                 __syncthreads();                                                // positions of all agents final
                 distance_pass<BLOCK, (CT ? AP : 0)>(p, l, Gv, tid, true);
                 __syncthreads();
+                STAMP(23);
                 if (mine) { if (rotfam) write_obs_rot<AP, SC>(p, v, i, ph1); else write_obs<AP, SC>(p, v, i, v.vox[i], v.voy[i], ph1); }
                 any_mask = 0;
                 for (int gg = 0; gg < Gv; ++gg) any_mask |= l.flags[gg * 4 + 2];

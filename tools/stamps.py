@@ -19,8 +19,9 @@ eng.reset()
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 acts = torch.randint(0, cfg.n_actions, (40, N, cfg.num_agents), generator=g, device="cuda", dtype=torch.int32)
 ROLLOUT = len(sys.argv) > 3 and sys.argv[3] == "roll"      # stamps of the LAST step of a K-step rollout launch (k_env<*, 0, SC, 2>)
+KROLL = int(sys.argv[4]) if len(sys.argv) > 4 else 37     # 25 (= episode_length): the stamped last step is the all-env auto-reset step
 if ROLLOUT:
-    eng.rollout(acts, 37)
+    eng.rollout(acts, KROLL)
 else:
     for k in range(20):
         eng.step(acts[k])
@@ -40,6 +41,9 @@ print("timeline (median cycles): load %d | F %d | dyn %d | dist %d | phase %d | 
 # slots 9 / 10: wave 1 (thread 64) right before / after its share of the graph stores (the issue of the stores, not their completion)
 print("streaming wave 1: starts %d cycles after the phase barrier, issues its stores for %d cycles (adjacency %d | node rows %d); wave 3: %d (adjacency %d | node rows %d); "
       "wave 0 finishes sections 3+4 %d cycles after the phase barrier" % (seg(5,9), seg(9,10), seg(9,16), seg(16,10), seg(17,18), seg(17,19), seg(19,18), seg(5,7)))
+print("reset-path segments (median cycles; non-reset steps: ~0): sec4 end -> reset done (S7->S8) %d | reset done -> graph stores issued (S8->S11) %d | -> end (S11->S12) %d" % (seg(7,8), seg(8,11), seg(11,12)))
+print("reset section split (median cycles): sec4 end -> placement start %d | placement (reset_world_coop) %d | barrier + per-agent re-init + state write-through %d | barrier + distance pass + barrier %d | re-observation %d" % (
+    seg(7,20), seg(20,21), seg(21,22), seg(22,23), seg(23,8)))
 print("blocks", nb, "G/BLOCK env:", os.environ.get("GMPE_G"), os.environ.get("GMPE_BLOCK"))
 tot = (s[:, 12] - s[:, 0])
 print("total cycles/block: median %d  p90 %d" % (np.median(tot), np.percentile(tot, 90)))
