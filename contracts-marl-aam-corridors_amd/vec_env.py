@@ -25,14 +25,14 @@ class LazyInfos(object):
     keys every step would dominate the host, so the dicts are created on first access.
     """
 
-    def __init__(self, info_dev, n_envs, n_agents, include_min_time=True, include_phase=False, owner=None, generation=0, errors=None):
+    def __init__(self, info_dev, n_envs, n_agents, include_min_time=True, include_phase=False, owner=None, generation=0):
         """info_dev: the device tensor the step wrote its info rows into. The vec env alternates TWO such tensors (no per-step clone), so
         the rows stay valid until the step after next; `owner` / `generation` let a late read fail loudly instead of returning a later
-        step's rows. errors: callable run at fetch time (the host synchronises there anyway): raises on sticky device error flags."""
+        step's rows."""
         self._dev = info_dev
         self._host = None
         self._n, self._a = n_envs, n_agents
-        self._owner, self._gen, self._errors = owner, generation, errors
+        self._owner, self._gen = owner, generation
         # (key, column) pairs: 'Min_time_to_goal' only with max_speed (…_july.py:826-828), 'Phase_reached' only in rot_inv (:835)
         self._keys = [(k, j) for j, k in enumerate(INFO_KEYS)
                       if (k != "Min_time_to_goal" or include_min_time) and (k != "Phase_reached" or include_phase)]
@@ -44,8 +44,6 @@ class LazyInfos(object):
                                    "before the step after next" % (self._gen, self._owner._info_gen))
             self._host = self._dev.detach().cpu().numpy().astype(np.float64)
             self._dev = None
-            if self._errors is not None:
-                self._errors()
         return self._host
 
     def __len__(self):
