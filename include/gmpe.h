@@ -235,7 +235,11 @@ int gmpe_step_many_launches(gmpe_handle* h, const int32_t* actions_dev, int32_t 
  * (the pointers in `slot0`). num_slots = 1 with zero strides = "every step overwrites the same buffers" (gmpe_step_many).
  * `masks` / `active_masks` (optional, f32 [slots][N,A], stride_masks apart) receive GraphReplayBuffer.insert's mask rules for the
  * step (see gmpe_masks_from_dones). Not available for handles on the split big-E path (gmpe_tuning.split): returns
- * GMPE_ERR_UNSUPPORTED there — use gmpe_step_many. */
+ * GMPE_ERR_UNSUPPORTED there — use gmpe_step_many.
+ * Performance note (round 3, profiles/r03_notes.md): with one slot every persistent workgroup rewrites its own output block each step; where a step's
+ * outputs are far larger than the 256 MiB Infinity Cache that is markedly slower than slot-per-step storage (c4, 6 GB per step: 1122 us per step with one
+ * slot, 929 with 4 slots, 868 with 26) — give big configurations the [T, ...] storage a rollout buffer has anyway. Outputs that fit the cache (c2 / c3:
+ * 98 MB per step) are faster with one slot (absorbed by the cache) but are then not paid in DRAM writes. */
 typedef struct gmpe_rollout {
     int32_t num_steps;          /* K >= 1                                                                  */
     int32_t num_action_sets;    /* S: step k uses action set k % S of actions_dev (i32 [S,N,A])            */
