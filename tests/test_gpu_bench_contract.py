@@ -84,3 +84,23 @@ def test_cpu_baseline_leg_and_other_workload():
 def test_smoke_entry():
     out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-2000:]
+
+
+def test_two_rank_rehearsal_of_the_multi_gpu_bench_path():
+    """The driver launches `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` on an 8-GPU node; this box has one GPU, so the same command runs
+    as a REHEARSAL — two ranks on the one GPU, gloo instead of RCCL (GMPE_BENCH_REHEARSAL=1) — to pin the multi-rank branch end to end: process-group init before any GPU
+    work, env-range sharding by rank (env_id_base), barrier + max-over-ranks timing, rank 0 printing ONE line, the rollout gather. No scaling claim follows from it."""
+    env = dict(os.environ, GMPE_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--reps", "2", "--workload", "c3", "--envs", "512",
+           "--gather", "--no-cpu-baseline", "--no-boundary"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout                        # only rank 0 prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "weak" and d["config"]["envs_per_gpu"] == 512
+    assert d["value"] > 0 and abs(d["value"] - 2 * 512 * 10 / (d["ms_per_step"] * 1e-3 * 10)) < 1e-6 * d["value"]     # whole-job aggregate over both ranks
+    assert d["with_gather"]["value"] > 0 and d["with_gather"]["slab_bytes_per_rank"] > 0
+    assert "cpu_baseline" not in d and "one_slot" not in d     # N = 1 only
