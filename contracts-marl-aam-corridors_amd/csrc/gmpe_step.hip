@@ -699,12 +699,12 @@ static int split_pipeline(gmpe_handle* h, int mode, KParams& p, float* adj_full,
     // chunk boundaries: equal chunks, except that the first two are a quarter and a half chunk (GMPE_RAMP) so that the expansion stream — the
     // bottleneck — starts after a quarter of a k_env chunk instead of a whole one. Chained steps: only for pipelines of >= 6 chunks per step (us per
     // step with / without: 1024 envs 729 / 697, 2048: 1375-1431 / 1350, 4096: 2750 / 2790, 8192: 5818 / 6000, 16384: 10941-11219 / 11327-11368)
-    int bounds[130]; int nb = 0;
+    int bounds[134]; int nb = 0;                                            // <= 128 chunks + the two ramp chunks + the end marker
     {
         const bool ramp = (h->ramp >= 0 ? h->ramp != 0 : (!chained || C >= 6)) && per >= 4 * h->G;   // GMPE_RAMP=0: equal chunks
         int lo = 0;
         if (ramp) { const int q = (per / 4 + h->G - 1) / h->G * h->G; bounds[nb++] = lo; lo += q; bounds[nb++] = lo; lo += 2 * q; }
-        while (lo < N && nb < 129) { bounds[nb++] = lo; lo += per; }
+        while (lo < N && nb < 132) { bounds[nb++] = lo; lo += per; }
         bounds[nb] = N;
         for (int q = 0; q < nb; ++q) if (bounds[q] > N) bounds[q] = N;
         // every env must be covered by a chunk that has its events: never step a truncated batch silently
