@@ -460,6 +460,14 @@ def main():
                          "isolated_launch_ms": iso,
                          "algorithmic_bytes_per_env_step": B, "env_steps_per_launch": env_steps_per_launch},
         }
+        # launch shape of the timed region, so that lines of different rounds compare like for like (round 1: one launch per step; round 2: one-slot rollout;
+        # round 3 on: rollout into slot-per-step storage) — the other shapes' rates ride along as top-level fields
+        out["launch_shape"] = {"rollout": "rollout_into_%d_slots" % n_slots if slots is not None else "rollout_one_slot", "launch-loop": "one_launch_per_step",
+                               "host-loop": "one_launch_per_step_python_loop"}[mode]
+        if one_slot is not None:
+            out["value_one_slot"] = n_envs / (one_slot["ms_per_step"] * 1e-3)
+        if closed is not None:
+            out["value_closed_loop"] = n_envs / (closed["ms_per_step"] * 1e-3)
         if one_slot is not None:
             one_slot["algorithmic_GBps"] = B * n_envs / (one_slot["ms_per_step"] * 1e-3) / 1e9
             if not one_slot["cache_resident"]:

@@ -44,6 +44,7 @@ def test_default_line_has_every_contract_field():
     assert rp["n"] == 3 and len(rp["env_steps_per_s"]) == 3 and sorted(rp["env_steps_per_s"])[1] == d["value"]   # the median is reported
     assert d["closed_loop"]["launches"] == 20 and d["closed_loop"]["ms_per_step"] > 0
     assert d["one_slot"]["launches"] == 1 and d["one_slot"]["ms_per_step"] > 0 and "frac" not in d["one_slot"]     # cache-resident overwrite: no HBM fraction
+    assert d["launch_shape"] == "rollout_into_26_slots" and d["value_one_slot"] > 0 and d["value_closed_loop"] > 0
     assert d["numpy_boundary"]["value"] > 1e5 and d["numpy_boundary"]["value"] < d["value"]
     assert d["value"] > 1e6                                  # BASELINE.json target on one MI355X
 
