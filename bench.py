@@ -57,7 +57,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
 HEADLINE_METRIC = "env-steps/sec (whole node) at 4096 envs x 10 agents, navigation_graph"     # BASELINE.json `metric` (configs[1] = c2)
 # Knobs that change which kernel instantiation / library runs. Performance knobs are recorded; result-changing ones are refused.
-PERF_KNOBS = ("GMPE_G", "GMPE_BLOCK", "GMPE_NT", "GMPE_SPEC", "GMPE_SPLIT", "GMPE_ROLL", "GMPE_GROLL", "GMPE_CHUNKS", "GMPE_RAMP", "GMPE_AP", "GMPE_ROLLNT", "GMPE_AHEAD", "GMPE_XSTEP")
+PERF_KNOBS = ("GMPE_G", "GMPE_BLOCK", "GMPE_NT", "GMPE_SPEC", "GMPE_SPLIT", "GMPE_ROLL", "GMPE_GROLL", "GMPE_CHUNKS", "GMPE_RAMP", "GMPE_AP", "GMPE_ROLLNT", "GMPE_AHEAD", "GMPE_XSTEP", "GMPE_FUSE")
 DIAG_KNOBS = ("GMPE_ABLATE", "GMPE_LIB")
 
 

@@ -37,6 +37,9 @@ struct KParams {
     int A, L, O, E, D, F;     // F = node features per row (8, rot_inv: 7)
     int G;                    // envs per workgroup (G*A <= 64)
     int spec;                 // 1: multi-wave tiles specialise (wave 0 reward/info, waves 1.. graph stores)
+    int rowpairs;             // 1: rollouts of exact-size tiles run distance_force_pass (agent-row pairs only, landmark block cached, navigation_graph: + next-step forces)
+    int nfuse;                // > 0: doubles per env of the separate pair-force buffer (2*A*A) — rollouts of exact-size navigation_graph tiles compute the NEXT
+                              // step's contact forces inside the distance pass (gmpe_create decides; 0: the force pass aliases the fp32 matrix)
     int nt;                   // 1: nontemporal graph stores (outputs per launch exceed the 256 MiB Infinity Cache)
     int ablate;               // diagnostic build only (-DGMPE_DIAG): timing-only ablations; the shipped library ignores it
     // rollout (FL == 2 instantiations, gmpe_rollout_steps): K steps inside one launch, state carried in LDS / registers
@@ -77,6 +80,7 @@ struct Lds {
     double *tube;                     // [G][12]
     double *Dm;                       // [G][A][E] fp64 agent->entity distances (rows of cached_dist_mag)
     double *fw;                       // [G][A][2*NW] wall contact forces (x, y per wall), walls variant only
+    double *F2;                       // [2][G][A][A] pair forces (x block, y block) that outlive the fp32 matrix (NF > 0: fused rollouts, see distance_force_pass)
     double *cntd;                     // [G][A][2] goal_min_time, prev_proj + [G] delta_spacing: staged by the loader lanes; + [G] int64 RNG counter after a reset (rollouts)
     int *s_old, *newf, *gt;           // [G][A]  status before, newly-reached flag, goal_tracker (final)
     int *dtg_o, *dtg_n, *trq_o, *trq_n, *sv_o, *sv_n;   // [G][A] info counters old/new
@@ -87,14 +91,14 @@ struct Lds {
     float *obs;                       // [G][A*D] staging
     float *M;                         // [G][E*E] masked distance matrix, fp32
 };
-__host__ __device__ inline size_t lds_bytes(int G, int A, int E, int D, int NW) {
+__host__ __device__ inline size_t lds_bytes(int G, int A, int E, int D, int NW, int NF = 0) {
     const size_t EE4 = ((size_t)E * E + 3) / 4 * 4, AD4 = ((size_t)A * D + 3) / 4 * 4;
-    size_t d = (size_t)G * (2 * E + 14 * A + 14 + (size_t)A * E + (size_t)A * 2 * NW);   // doubles
+    size_t d = (size_t)G * (2 * E + 14 * A + 14 + (size_t)A * E + (size_t)A * 2 * NW + (size_t)NF);   // doubles
     size_t f = (size_t)G * (EE4 + AD4);                             // floats
     size_t i = (size_t)G * (18 * A + 4 + E) + (size_t)A * (A - 1) / 2 + 1;   // ints
     return d * 8 + 16 + f * 4 + ((i * 4 + 15) / 16) * 16 + 32;
 }
-__device__ inline Lds carve(char* base, int G, int A, int E, int D, int NW) {
+__device__ inline Lds carve(char* base, int G, int A, int E, int D, int NW, int NF = 0) {
     Lds l;
     double* d = reinterpret_cast<double*>(base);
     l.ex = d; d += G * E; l.ey = d; d += G * E;
@@ -103,6 +107,7 @@ __device__ inline Lds carve(char* base, int G, int A, int E, int D, int NW) {
     l.serr = d; d += G * A; l.cn = d; d += G * A; l.sn = d; d += G * A; l.rew = d; d += G * A; l.tube = d; d += G * 12;
     l.Dm = d; d += (size_t)G * A * E;
     l.fw = d; d += (size_t)G * A * 2 * NW;
+    l.F2 = d; d += (size_t)G * NF;
     l.cntd = d; d += (size_t)G * (2 * A + 2);
     if ((uintptr_t)d & 15) d += 1;
     float* f = reinterpret_cast<float*>(d);
@@ -123,7 +128,7 @@ __device__ inline Lds env_view(const Lds& l, int g, int A, int E, int D) {
     v.s2 = l.s2 + g * A; v.s3 = l.s3 + g * A; v.n2 = l.n2 + g * A; v.n3 = l.n3 + g * A;
     v.vox = l.vox + g * A; v.voy = l.voy + g * A; v.vnx = l.vnx + g * A; v.vny = l.vny + g * A;
     v.serr = l.serr + g * A; v.cn = l.cn + g * A; v.sn = l.sn + g * A; v.rew = l.rew + g * A; v.tube = l.tube + g * 12;
-    v.Dm = l.Dm + (size_t)g * A * E; v.fw = l.fw; v.cntd = l.cntd; v.cnt = l.cnt;      // fw / cnt / cntd are indexed with the tile-level agent slot
+    v.Dm = l.Dm + (size_t)g * A * E; v.fw = l.fw; v.F2 = l.F2; v.cntd = l.cntd; v.cnt = l.cnt;      // fw / cnt / cntd are indexed with the tile-level agent slot
     v.s_old = l.s_old + g * A; v.newf = l.newf + g * A; v.gt = l.gt + g * A;
     v.dtg_o = l.dtg_o + g * A; v.dtg_n = l.dtg_n + g * A; v.trq_o = l.trq_o + g * A; v.trq_n = l.trq_n + g * A;
     v.sv_o = l.sv_o + g * A; v.sv_n = l.sv_n + g * A; v.flags = l.flags + g * 4; v.moff = l.moff + g * E; v.ptab = l.ptab;
@@ -499,6 +504,69 @@ __device__ __forceinline__ void distance_pass(const KParams& p, const Lds& l, in
 #define STAMP(k) do { } while (0)
 #define STAMP_T(k, t) do { } while (0)
 #endif
+// Rollouts of exact-size navigation_graph tiles (A = L = CA, no obstacles, no walls): the distance pass of step k ALSO computes the contact forces of step
+// k + 1 (get_entity_collision_force, core.py:872-906) — the positions after step k's move are the positions step k + 1's force pass would read, the pair
+// (a, k > a) and its delta pos[a] - pos[k] are the same, so the values are bit-identical — and it visits only the pairs that change: agent x agent and agent x
+// landmark (145 of an env's 190); the landmark x landmark block of the fp32 matrix is built once per launch / reset (`statics`) and stays (its mask only grows
+// between resets). One fp64 sqrt per agent pair instead of two, 24 % fewer pairs per step, and the separate force pass with its barrier disappears from the
+// step. Pair order across the tile: all envs' agent pairs first (their softplus code then runs in the first trip of the first waves only), then the
+// agent x landmark pairs, then the statics. The forces go to a buffer of their own (F2): they outlive the fp32 matrix the classic force pass aliases.
+template <int BLOCK, int CA, bool FORCES>
+__device__ __forceinline__ void distance_force_pass(const KParams& p, const Lds& l, int G, int Gv, int tid, bool only_reset, bool statics) {
+    constexpr int A = CA, E = 2 * CA, AE = A * E, EE4 = (E * E + 3) / 4 * 4, NP = A * (A - 1) / 2, NL = A * A;
+    const gmpe_config& c = p.c;
+    double* Fx = l.F2; double* Fy = Fx + (size_t)G * A * A;
+    const int n1 = Gv * NP, n2 = n1 + Gv * NL, total = n2 + (statics ? Gv * NP : 0);
+    const int wave_base = tid & ~63;
+    for (int base = 0; base + wave_base < total; base += 3 * BLOCK) {
+        double ds[3], dxs[3], dys[3]; int gs[3], rs[3], cs[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int q = base + u * BLOCK + tid;
+            const bool live = q < total;
+            const int qq = live ? q : 0;
+            int g, r, cc;
+            if (qq < n1) { g = qq / NP; const int pk = l.ptab[qq - g * NP]; r = pk >> 8; cc = pk & 255; }                 // agent pair (a < k)
+            else if (qq < n2) { const int t = qq - n1; g = t / NL; const int w = t - g * NL; r = w / A; cc = A + (w - r * A); }   // agent x landmark
+            else { const int t = qq - n2; g = t / NP; const int pk = l.ptab[t - g * NP]; r = A + (pk >> 8); cc = A + (pk & 255); }   // landmark pair (L = A)
+            const double dx = l.ex[g * E + r] - l.ex[g * E + cc], dy = l.ey[g * E + r] - l.ey[g * E + cc];   // pos[min] - pos[max] (core.py:600-624)
+            dxs[u] = dx; dys[u] = dy; ds[u] = sqrt(dx * dx + dy * dy);
+            gs[u] = (live && !(only_reset && !l.flags[g * 4 + 0])) ? g : -1; rs[u] = r; cs[u] = cc;
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            if (gs[u] < 0) continue;
+            const int r = rs[u], cc = cs[u];
+            float* Mg = l.M + (size_t)gs[u] * EE4;
+            const float df = (float)ds[u];
+            Mg[r * E + cc] = df; Mg[cc * E + r] = df;
+            if (r < A) {
+                double* Dg = l.Dm + (size_t)gs[u] * AE;
+                Dg[r * E + cc] = ds[u];
+                if (cc < A) Dg[cc * E + r] = ds[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            if (!FORCES) break;                                               // kinematic scenarios: no contact forces, only the pair set shrinks
+            if (base + u * BLOCK + wave_base >= n1) continue;                 // wave-uniform: this trip of this wave holds no agent pair
+            if (gs[u] < 0 || cs[u] >= A) continue;
+            // d_min: multiagent/core.py:880 COLLISION_DISTANCE; classic MPE (onpolicy/envs/mpe/core.py:276, 282) size_a + size_b
+            const double dmin = c.contact_family ? c.agent_size + c.agent_size : c.sep_dist;
+            const double pen = logaddexp0(-(ds[u] - dmin) / c.contact_margin) * c.contact_margin;
+            const int slot = gs[u] * A * A + rs[u] * A + cs[u];
+            Fx[slot] = c.contact_force * dxs[u] / ds[u] * pen; Fy[slot] = c.contact_force * dys[u] / ds[u] * pen;
+        }
+    }
+    for (int q = tid; q < G * E; q += BLOCK) {                           // diagonal
+        const int g = q / E, r = q - g * E;
+        if (only_reset && !l.flags[g * 4 + 0]) continue;
+        if (r >= A && !statics) continue;
+        l.M[(size_t)g * EE4 + r * E + r] = 0.0f;
+        if (r < A) l.Dm[(size_t)g * AE + r * E + r] = 0.0;
+    }
+}
+
 #define SWEEP(var, n) _Pragma("unroll") for (int var = 0; var < (AP ? AP : (n)); ++var)
 // Graph outputs of a tile: optional adjacency mask pass (block-wide, with its barrier), then the adj and node_obs
 // stores executed by threads t0, t0+nthr, ... (all BLOCK threads, or only the streaming waves of a specialised tile).
@@ -702,7 +770,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
     constexpr bool CT = AP > 0 && SC != SC_NAV_WALLS;     // host: AP > 0 only if A == L == AP and O == 0
     const int A = CT ? AP : p.A, L = CT ? AP : p.L, O = CT ? 0 : p.O, E = CT ? 2 * AP : p.E, D = CT ? (SC == SC_JULY ? 19 : (sc_phasefam(SC) ? 15 : 13)) : p.D, G = p.G, N = p.c.num_envs;
     const gmpe_config& c = p.c;
-    const Lds l = carve(smem, G, A, E, D, SC == SC_NAV_WALLS ? p.c.num_walls : 0);
+    const Lds l = carve(smem, G, A, E, D, SC == SC_NAV_WALLS ? p.c.num_walls : 0, p.nfuse);
     const int n0 = p.env_lo + blockIdx.x * G;
     const int Gv = min(G, p.env_hi - n0);                               // envs actually present in this tile
     constexpr bool july = SC == SC_JULY, rotinv = SC == SC_ROT, rotfam = sc_rotfam(SC), two = SC == SC_TWO, three = SC == SC_THREE;
@@ -809,6 +877,9 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
     // graph stores of step k drain while the tile — and the other tiles of the CU, which drift out of phase — run step k+1's
     // latency chain. Every other instantiation runs the body once.
     constexpr bool ROLL = FL == 2;
+    // the instantiations that can run distance_force_pass: exact-size rollout tiles (A = L = AP, no obstacles); navigation_graph fuses the next step's force pass into it
+    constexpr bool FUSE_OK = ROLL && SC != SC_NAV_WALLS && AP > 0 && BLOCK > 64;
+    const bool FUSE = FUSE_OK && p.rowpairs != 0 && (kin || p.nfuse > 0);
     const int K = ROLL ? p.K : 1;
     int slot = ROLL ? p.first_slot : 0, aset = 0;
     const int tid_o = tid; const bool ag_o = ag;
@@ -854,9 +925,9 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
         if (step) {
             cur_step += 1;
             const int C = A + O;                                            // colliders: agents + obstacles (landmarks collide=False)
-            double* Fx = reinterpret_cast<double*>(l.M);                    // pair forces alias the (not yet built) fp32 matrix
+            double* Fx = FUSE ? l.F2 : reinterpret_cast<double*>(l.M);      // pair forces alias the (not yet built) fp32 matrix, except in fused rollouts
             double* Fy = Fx + (size_t)G * A * C;
-            if (!kin) {
+            if (!kin && !(FUSE && kk > 0)) {                                // fused rollouts: the previous step's distance pass left this step's forces in F2
                 // ---- 1a. contact forces, one PAIR per lane (get_entity_collision_force core.py:872-906): pair (a, k>a)
                 // computed once with delta = pos[a]-pos[k]; side a gets +F, side k gets -F (summed in 1b).
                 const int NP = A * (A - 1) / 2, W = NP + A * O;            // valid pairs only: agent pairs (a<k) + agent x obstacle
@@ -962,7 +1033,10 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
             }
             __syncthreads();
             STAMP(3);
-            distance_pass<BLOCK, (CT ? AP : 0)>(p, l, Gv, tid, false);                    // post-move rows: obs, reward, info, adj all read these
+            if constexpr (FUSE_OK) {
+                if (FUSE) distance_force_pass<BLOCK, AP, !kin>(p, l, G, Gv, tid, false, kk == 0);   // + the next step's contact forces
+                else distance_pass<BLOCK, (CT ? AP : 0)>(p, l, Gv, tid, false);
+            } else distance_pass<BLOCK, (CT ? AP : 0)>(p, l, Gv, tid, false);             // post-move rows: obs, reward, info, adj all read these
             __syncthreads();
             STAMP(4);
 
@@ -1353,7 +1427,10 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
                 }
                 STAMP(22);
                 __syncthreads();                                                // positions of all agents final
-                distance_pass<BLOCK, (CT ? AP : 0)>(p, l, Gv, tid, true);
+                if constexpr (FUSE_OK) {
+                    if (FUSE) distance_force_pass<BLOCK, AP, !kin>(p, l, G, Gv, tid, true, true);   // the reset envs' rows, statics and next-step forces
+                    else distance_pass<BLOCK, (CT ? AP : 0)>(p, l, Gv, tid, true);
+                } else distance_pass<BLOCK, (CT ? AP : 0)>(p, l, Gv, tid, true);
                 __syncthreads();
                 STAMP(23);
                 if (mine) { if (rotfam) write_obs_rot<AP, SC>(p, v, i, ph1); else write_obs<AP, SC>(p, v, i, v.vox[i], v.voy[i], ph1); }

@@ -246,6 +246,8 @@ struct gmpe_handle {
     int ahead = 0;                       // k_env may run at most this many chunks ahead of the expansion (0: unbounded)
     int xstep = 0;                       // gmpe_step_many on the split path: chain the steps' pipelines (no join between steps)
     int chunks_x = 1, ahead_x = 0;       // chunking / run-ahead bound of the chained pipeline
+    int rowpairs = 0;                    // rollouts of the exact-size instantiations visit agent-row pairs only (distance_force_pass)
+    int nfuse = 0;                       // doubles per env of the separate pair-force buffer (fused rollouts of exact-size navigation_graph tiles), 0: none
     int ramp = -1;                       // GMPE_RAMP, read once by gmpe_create (-1: the default rule of split_pipeline)
     unsigned long long* stamps = nullptr;
     hipEvent_t region_ev[2] = {nullptr, nullptr};
@@ -420,8 +422,13 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     // (C4/C5, N >> 4096) a tile packs as many envs as wave 0 holds (G*A <= 64) and the stores decide.
     int dev_cus = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) dev_cus = prop.multiProcessorCount; }
+    // Rollouts of the exact-size navigation_graph instantiation (A = L = 10, no obstacles, no walls) compute the next step's contact forces inside the distance
+    // pass (distance_force_pass): the forces then need a buffer of their own, 2*A*A doubles per env (1.6 KB). GMPE_FUSE=0: the classic force pass.
+    h->nfuse = (sc_of(h->c) == SC_NAV && h->A == h->L && h->O == 0 && h->A == 10 && !(getenv("GMPE_AP") && atoi(getenv("GMPE_AP")) == 0)) ? 2 * h->A * h->A : 0;
+    if (getenv("GMPE_FUSE") && atoi(getenv("GMPE_FUSE")) == 0) h->nfuse = 0;
+    h->rowpairs = (getenv("GMPE_FUSE") && atoi(getenv("GMPE_FUSE")) == 0) ? 0 : 1;
     int Gmax = 64 / h->A; if (Gmax < 1) Gmax = 1; if (Gmax > (int)N) Gmax = (int)N;
-    while (Gmax > 1 && lds_bytes(Gmax, h->A, E, h->D, cfg->num_walls) > 48 * 1024) --Gmax;
+    while (Gmax > 1 && lds_bytes(Gmax, h->A, E, h->D, cfg->num_walls, h->nfuse) > 48 * 1024) --Gmax;
     int ap_sel = (h->A == h->L && h->O == 0 && (h->A == 10 || h->A == 3)) ? h->A : 0;   // exact-size instantiations of the common cases (A = L, no obstacles)
     if (getenv("GMPE_AP") && atoi(getenv("GMPE_AP")) == 0) ap_sel = 0;                    // tuning: run-time sizes
     h->ap = ap_sel;
@@ -433,7 +440,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
         for (int bi = 0; bi < 3 && !G; ++bi)
             for (int g = G0; g <= Gmax; ++g) {
                 const size_t tiles = (N + g - 1) / g;
-                const int per_cu = sc_dispatch_occ(sc_of(h->c), blocks[bi], ap_sel, lds_bytes(g, h->A, E, h->D, cfg->num_walls));
+                const int per_cu = sc_dispatch_occ(sc_of(h->c), blocks[bi], ap_sel, lds_bytes(g, h->A, E, h->D, cfg->num_walls, h->nfuse));
                 if (per_cu > 0 && tiles <= (size_t)per_cu * dev_cus) { G = g; block_sel = blocks[bi]; break; }
             }
     }
@@ -460,7 +467,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
             if (G0 < 1) G0 = 1;
             for (int g = G0; g <= Gmax && !Gr; ++g) {
                 const size_t tiles = (N + g - 1) / g;
-                const int per_cu = sc_dispatch_occ(sc_of(h->c), h->block_roll, ap_sel, lds_bytes(g, h->A, E, h->D, cfg->num_walls), 1);
+                const int per_cu = sc_dispatch_occ(sc_of(h->c), h->block_roll, ap_sel, lds_bytes(g, h->A, E, h->D, cfg->num_walls, h->nfuse), 1);
                 if (per_cu > 0 && tiles <= (size_t)per_cu * dev_cus) Gr = g;
             }
         }
@@ -484,7 +491,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
         // adjacency is >= ~95 % of the bytes (A >= 48): c5 shapes (64 agents) 2048 envs 1515 us split vs 1731 fused, 4096: 2994 vs 3455,
         // 8192: 6043 vs 6565, 16384: 11618 vs 12981 (with the run-ahead bound below); c4 (A = 32) 1260 vs 1132: stays fused
         // (profiles/r02_notes.md). Everything else runs the fused kernel.
-        const size_t tiles_resident = (size_t)dev_cus * (size_t)[&] { const int q = sc_dispatch_occ(sc_of(h->c), block_sel ? block_sel : 256, ap_sel, lds_bytes(G, h->A, E, h->D, cfg->num_walls)); return q > 0 ? q : 1; }();
+        const size_t tiles_resident = (size_t)dev_cus * (size_t)[&] { const int q = sc_dispatch_occ(sc_of(h->c), block_sel ? block_sel : 256, ap_sel, lds_bytes(G, h->A, E, h->D, cfg->num_walls, h->nfuse)); return q > 0 ? q : 1; }();
         const size_t tiles_total = (N + G - 1) / G;
         h->split = getenv("GMPE_SPLIT") ? atoi(getenv("GMPE_SPLIT"))
                                         : (out_bytes > 192.0 * 1024 * 1024 && h->A >= 48 ? 1 : 0);
@@ -546,7 +553,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     // Multi-wave tiles specialise (wave 0: reward / info / write-back, waves 1..: graph stores). Measured with the final register
     // budgets: C2 30.2 vs 33.2 us, C4 1286 vs 1297 us, C5 shard 1901 vs 1970 us — on everywhere (GMPE_SPEC=0 turns it off).
     h->spec = getenv("GMPE_SPEC") ? atoi(getenv("GMPE_SPEC")) : 1;
-    const size_t lds = lds_bytes(h->G > h->G_roll ? h->G : h->G_roll, h->A, E, h->D, cfg->num_walls);
+    const size_t lds = lds_bytes(h->G > h->G_roll ? h->G : h->G_roll, h->A, E, h->D, cfg->num_walls, h->nfuse);
     if (lds > 160 * 1024) { gmpe_destroy(h); return fail(GMPE_ERR_UNSUPPORTED, "per-tile LDS exceeds 160 KiB"); }
     if (lds > 48 * 1024) {                                   // opt in to >64 KiB dynamic LDS (gfx950: 160 KiB per CU)
         const hipError_t e = sc_dispatch_lds(sc_of(h->c), (int)lds);
@@ -648,6 +655,7 @@ static void fill_params(const gmpe_handle* h, KParams& p, int G) {
     p.A = h->A; p.L = h->L; p.O = h->O; p.E = h->E; p.D = h->D; p.F = h->F; p.G = G;
     p.ablate = h->ablate;
     p.nt = h->nt;
+    p.nfuse = h->nfuse; p.rowpairs = h->rowpairs;
     p.spec = h->spec;
     p.stamps = h->stamps;
     p.K = 1; p.S = 1; p.num_slots = 1;
@@ -663,7 +671,7 @@ static void fill_params(const gmpe_handle* h, KParams& p, int G) {
 }
 static int ap_of(const gmpe_handle* h) { return h->ap; }
 static void dispatch_env(const gmpe_handle* h, int block, int ap, int fl, hipStream_t st, const KParams& p) {
-    const size_t lds = lds_bytes(p.G, h->A, h->E, h->D, h->c.num_walls);
+    const size_t lds = lds_bytes(p.G, h->A, h->E, h->D, h->c.num_walls, h->nfuse);
     const dim3 grid((p.env_hi - p.env_lo + p.G - 1) / p.G);
     switch (sc_of(h->c)) {
         case SC_NAV: launch_env<SC_NAV>(block, ap, fl, grid, lds, st, p); break;
@@ -796,7 +804,7 @@ int gmpe_get_tuning(const gmpe_handle* h, gmpe_tuning* t) {
     if (!h || !t) return fail(GMPE_ERR_INVALID_ARG, "gmpe_get_tuning: null argument");
     memset(t, 0, sizeof *t);
     t->G = h->G; t->block = h->block; t->nt = h->nt; t->spec = h->spec; t->split = h->split; t->roll = h->roll; t->ap = ap_of(h);
-    t->lds_bytes = (int32_t)lds_bytes(h->G, h->A, h->E, h->D, h->c.num_walls);
+    t->lds_bytes = (int32_t)lds_bytes(h->G, h->A, h->E, h->D, h->c.num_walls, h->nfuse);
     t->G_roll = h->G_roll; t->block_roll = h->block_roll;
     t->chunks = h->split ? h->chunks : 0; t->ahead = h->split ? h->ahead : 0;
     t->xstep = h->split ? h->xstep : 0; t->chunks_x = h->split ? h->chunks_x : 0; t->ahead_x = h->split ? h->ahead_x : 0;

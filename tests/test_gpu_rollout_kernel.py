@@ -239,3 +239,48 @@ def test_rollout_nontemporal_store_variant_equals_step_loop(monkeypatch):
             for key in OUT_KEYS:
                 assert torch.equal(st[key][k], ref[k][key]), (scen, key, k)
         _compare_state(e1, e2, scen)
+
+
+@pytest.mark.parametrize("fuse", ["1", "0"])
+def test_fused_force_pass_with_goals_reached_mid_rollout(monkeypatch, fuse):
+    """Rollouts of the exact-size navigation_graph tile compute the next step's contact forces inside the distance pass and keep the landmark x landmark block of the
+    adjacency across steps (distance_force_pass; GMPE_FUSE=0: the classic passes). Agents parked on their goals reach them in the first steps, so the masks of reached
+    landmarks must persist on the cached block, colliding agents exercise the forces, short episodes put resets inside the rollout: every step's outputs must equal
+    the step loop's bit for bit, and the oracle's."""
+    import torch
+    monkeypatch.setenv("GMPE_FUSE", fuse)
+    cfg = gmpe.make_config(scenario_name="navigation_graph", num_envs=37, num_agents=10, world_size=4.0, episode_length=9, seed=123)
+    e1, e2, orc = _engine(cfg), _engine(cfg), ol.Oracle(cfg)
+    e1.reset(); e2.reset(); orc.reset()
+    # park agents 0..3 of every second env next to their own landmarks (inside goal_thresh) and put agents 4 / 5 on top of each other's edge (contact force)
+    lm = e1.get("landmarks"); x = e1.get("x"); y = e1.get("y")
+    for n in range(0, 37, 2):
+        for a in range(4):
+            x[n, a] = lm[n, a, 0] + 0.01 * (a + 1); y[n, a] = lm[n, a, 1] - 0.02
+        x[n, 5] = x[n, 4] + 0.3; y[n, 5] = y[n, 4] + 0.1
+    for e in (e1, e2, orc):
+        e.set("x", x); e.set("y", y)
+    K, T = 21, 21
+    rng = np.random.RandomState(9)
+    acts_np = rng.randint(0, cfg.n_actions, (K, 37, 10)).astype(np.int32)
+    acts = torch.as_tensor(acts_np, device="cuda")
+    ref = {k: [] for k in OUT_KEYS}
+    for k in range(K):
+        o = e1.step(acts[k])
+        for key in OUT_KEYS:
+            ref[key].append(getattr(o, key).clone())
+    st = _rollout_into_slots(e2, acts, K, T)
+    torch.cuda.synchronize()
+    for k in range(K):
+        for key in OUT_KEYS:
+            assert torch.equal(st[key][k], ref[key][k]), (key, k)
+        oo = orc.step(acts_np[k])
+        np.testing.assert_allclose(_np(st["adj"][k]), np.broadcast_to(oo[3][:, None], st["adj"][k].shape), rtol=0, atol=TOL, err_msg="adj %d" % k)
+        np.testing.assert_allclose(_np(st["obs"][k]), oo[0], rtol=0, atol=TOL, err_msg="obs %d" % k)
+        np.testing.assert_array_equal(_np(st["done"][k]).astype(bool), oo[5], err_msg="done %d" % k)
+    # masked landmark rows really occurred: some landmark x landmark block entries are zero off the diagonal in the first steps
+    blk = _np(st["adj"][1])[0, 0, 10:, 10:]
+    assert (blk[np.triu_indices(10, 1)] == 0).any()
+    _compare_state(e1, e2, "after fused rollout")
+    assert e2.tuning()["ap"] == 10
+    e1.check_errors(); e2.check_errors()
