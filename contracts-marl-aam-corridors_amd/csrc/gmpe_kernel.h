@@ -604,10 +604,15 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
             } else for (int q = t0; q < Gv * EE; q += nthr) { const int gg = fdiv(q, EE, p.m_EE); if (l.flags[gg * 4 + 3]) dst[q] = l.M[(size_t)gg * EE4 + (q - gg * EE)]; }
         } else {
             float* dst = o.adj + (size_t)n0 * A * EE;
+#ifdef GMPE_NTORDER_KNOB
+            if (vec && nt && p.ablate != 200) {                              // experiment build (tools/ntorder.py): GMPE_ABLATE=200 forces the lane-keeps-a-float4 order
+#else
             if (vec && nt) {
-                // big launches (nontemporal stores): OUTPUT order — the tile writes each env's [A,E,E] block front to back, so the
+#endif
+                // big graphs (nontemporal stores): OUTPUT order — the tile writes each env's [A,E,E] block front to back, so the
                 // workgroups in flight stream whole 0.6-4 MB blocks like a fill (tools/expandbw.hip: 6.9 vs 5.7 TB/s for the
-                // lane-keeps-a-float4 order below, whose A copies open A write fronts per tile)
+                // lane-keeps-a-float4 order below, whose A copies open A write fronts per tile). Also at small E: decided inside one process on one set
+                // of slot buffers (tools/ntorder.py: c2 19.4 vs 19.75 us per step, c3 18.4 vs 19.1) — across processes slot rollouts spread +-5 %
                 const int nq = EE / 4, per = A * nq;
                 for (int gg = 0; gg < Gv; ++gg) {
                     if (!l.flags[gg * 4 + 3]) continue;

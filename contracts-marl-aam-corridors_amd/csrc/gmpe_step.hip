@@ -476,7 +476,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
         if (Gr > Gmax) Gr = Gmax;
         h->G_roll = Gr;
     }
-#ifdef GMPE_DIAG
+#if defined(GMPE_DIAG) || defined(GMPE_NTORDER_KNOB)
     h->ablate = getenv("GMPE_ABLATE") ? atoi(getenv("GMPE_ABLATE")) : 0;   // diagnostic build only: timing ablations (wrong results)
 #else
     h->ablate = 0;
