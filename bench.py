@@ -180,6 +180,69 @@ def numpy_boundary(wl, n_envs, device, steps=30):
                     "adj (zero-copy broadcast of the compact matrix) / reward / done out (pinned D2H); PCIe-inclusive, never `value`"}
 
 
+def verify_timed_region(eng, cfg, snap, action_of_step, K, read_step, surviving_steps, n_verify):
+    """Checker for the launch the line is timed on: the CPU oracle (test infrastructure, loaded here as the checker only, after
+    the timed region) restarts the first `n_verify` envs from `snap` — the engine's persistent state right before the LAST timed repetition —, replays that
+    repetition's K action sets and must reproduce (a) every output of every step whose slot survives in the storage the timed launch wrote and (b) the
+    engine's final state: floats within 1e-5 (north_star), integer state / dones / agent ids / RNG counters bit-exact. Returns the `verified` object;
+    raises AssertionError on a mismatch."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import gmpe
+    import oracle_lib as ol
+    from gmpe.config import FIELDS
+    n = n_verify
+    c = type(cfg)()
+    import ctypes
+    ctypes.memmove(ctypes.byref(c), ctypes.byref(cfg), ctypes.sizeof(cfg))
+    c.num_envs = n                                                          # same seed / env_id_base: env ids [base, base + n) are the engine's first n envs
+    orc = ol.Oracle(c)
+    for k in FIELDS:
+        orc.set(k, snap[k][:n])
+    keep = set(surviving_steps)
+    worst = {"obs": 0.0, "node_obs": 0.0, "adj": 0.0, "reward": 0.0, "info": 0.0}
+    ints_exact = True
+    n_checked = 0
+    resets = 0
+    for k in range(K):
+        obs, ids, node, adj, rew, done, info, did = orc.step(action_of_step(k)[:n])
+        resets += int(did.sum())
+        if k not in keep:
+            continue
+        got = read_step(k)                                                   # dict of numpy arrays, first n envs
+        n_checked += 1
+        A, E = cfg.num_agents, cfg.num_entities
+        adj_ref = adj if got["adj"].ndim == 3 else np.broadcast_to(adj[:, None], (n, A, E, E))
+        for name, ref in (("obs", obs), ("node_obs", node), ("adj", adj_ref), ("reward", rew)):
+            worst[name] = max(worst[name], float(np.abs(got[name].astype(np.float64) - ref).max()))
+        assert np.array_equal(got["adj"] == 0, adj_ref == 0), "step %d: masked adjacency entries differ" % k
+        if got.get("info") is not None:
+            err = np.abs(got["info"].astype(np.float64) - info) / (1.0 + np.abs(info))
+            worst["info"] = max(worst["info"], float(err.max()))
+        ok = np.array_equal(got["done"].astype(bool), done) and np.array_equal(got["agent_id"].reshape(n, A), ids.reshape(n, A))
+        ints_exact = ints_exact and ok
+        assert ok, "step %d: done / agent_id differ from the oracle" % k
+    fin = eng.get_state()
+    state_err = 0.0
+    for k, (_, dt, _) in FIELDS.items():
+        a, b = fin[k][:n], orc.get(k)
+        if np.issubdtype(dt, np.floating):
+            state_err = max(state_err, float(np.abs(a - b).max()) if a.size else 0.0)
+        else:
+            same = np.array_equal(a, b)
+            ints_exact = ints_exact and same
+            assert same, "final state field %r differs from the oracle" % k
+    max_out = max(worst["obs"], worst["node_obs"], worst["adj"], worst["reward"])
+    assert max_out <= 1e-5, "outputs differ from the oracle: %r" % worst
+    assert worst["info"] <= 2e-5, "info rows differ from the oracle: %r" % worst
+    assert state_err <= 1e-5, "final float state differs from the oracle by %g" % state_err
+    orc.close()
+    return {"envs": n, "steps": K, "steps_compared": n_checked, "max_abs_err": max_out, "max_abs_err_by_output": worst, "max_abs_err_final_state": state_err,
+            "ints_exact": bool(ints_exact), "auto_resets_inside": resets, "tolerance": 1e-5,
+            "what": "CPU oracle restarted from the engine's state before the LAST timed repetition, fed that repetition's actions: every output of the "
+                    "steps whose slots survive in the storage the timed launch wrote + the final persistent state (ints / dones / RNG counters exact)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,8 +259,10 @@ def main():
     ap.add_argument("--host-loop", action="store_true", help="timed region = gmpe_step called from Python once per step (closed-loop shape)")
     ap.add_argument("--launch-loop", action="store_true", help="timed region = one launch per step enqueued by one C call (hipGraph of K kernel nodes)")
     ap.add_argument("--slots", type=int, default=None, help="rollout output slots (default: 26 = slot-per-step storage [26, ...] as DeviceRolloutBuffer keeps it, "
-                    "so every step's bytes are certainly paid in HBM writes; 1 where 26 steps of outputs do not fit 8 GiB). 1 = every step overwrites the same buffers")
+                    "so every step's bytes are certainly paid in HBM writes; fewer where 26 steps of outputs exceed min(75 %% of the free HBM, 200 GB) — "
+                    "c4 allocates 158 GB —, one slot below 4). 1 = every step overwrites the same buffers")
     ap.add_argument("--gather", action="store_true", help="also time step + RCCL gather of the compact rollout slab to rank 0")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-region oracle check of the timed launch's outputs (`verified`)")
     ap.add_argument("--diag", action="store_true", help="allow GMPE_LIB / GMPE_ABLATE (diagnostic A/B runs; recorded in the line, never a result)")
     args = ap.parse_args()
 
@@ -320,8 +385,30 @@ def main():
         return el, eng.region_ms()
 
     run_k_steps(K); torch.cuda.synchronize(dev)                     # untimed: first use of this launch shape (same K: every rollout launch of a run is alike)
-    reps = [timed(run_k_steps, K) for _ in range(R)]
+    do_verify = rank == 0 and not args.no_verify and not args.diag
+    reps, snap = [], None
+    for r in range(R):
+        if r == R - 1 and do_verify:
+            snap = eng.get_state()                                   # between two timed regions (both bracketed by synchronize): the state the last repetition starts from
+        reps.append(timed(run_k_steps, K))
     eng.check_errors()
+    verified = None
+    if do_verify:
+        # ---- outside every timed region: what did the last timed repetition write? (the number sits on a launch nothing else compares at this size)
+        n_ver = min(n_envs, 64 if cfg.num_agents <= 16 else (16 if cfg.num_agents <= 32 else 8))
+        acts_host = actions.cpu().numpy()
+        act_of = (lambda k: acts_host[(W + k) % n_act_sets]) if mode == "host-loop" else (lambda k: acts_host[k % n_act_sets])
+        if slots is not None:
+            surviving = range(max(0, K - n_slots), K)                # step k -> slot k % n_slots (first_slot 0): the last n_slots steps survive
+            read = lambda k: {key: v[k % n_slots][:n_ver].cpu().numpy() for key, v in slots.items()}
+        else:
+            surviving = [K - 1]                                       # every step overwrites the same buffers
+            read = lambda k: {key: getattr(eng.out, key)[:n_ver].cpu().numpy() for key in out_keys}
+        try:
+            verified = verify_timed_region(eng, cfg, snap, act_of, K, read, surviving, n_ver)
+        except AssertionError as e:
+            sys.exit("bench.py: the timed launch's outputs do NOT match the CPU oracle: %s" % e)
+        verified["launch"] = mode + (" into %d slots" % n_slots if slots is not None else "")
     order = sorted(range(R), key=lambda q: reps[q][0])
     med = order[(R - 1) // 2]                                        # the median repetition (lower median for even R)
     el, region_ms = reps[med]
@@ -480,6 +567,8 @@ def main():
             if "two_ranges_ms_per_step" in closed:
                 closed["two_ranges_frac"] = B * n_envs / (closed["two_ranges_ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             out["closed_loop"] = closed
+        if verified is not None:
+            out["verified"] = verified
         if gather is not None:
             out["with_gather"] = gather
         if world == 1 and not args.no_boundary:

@@ -35,7 +35,8 @@ class GmpeRollout(C.Structure):
 class GmpeTuning(C.Structure):
     _fields_ = [("G", C.c_int32), ("block", C.c_int32), ("nt", C.c_int32), ("spec", C.c_int32), ("split", C.c_int32),
                 ("roll", C.c_int32), ("ap", C.c_int32), ("lds_bytes", C.c_int32), ("diag_build", C.c_int32),
-                ("G_roll", C.c_int32), ("block_roll", C.c_int32), ("chunks", C.c_int32), ("ahead", C.c_int32), ("xstep", C.c_int32), ("chunks_x", C.c_int32), ("ahead_x", C.c_int32)]
+                ("G_roll", C.c_int32), ("block_roll", C.c_int32), ("chunks", C.c_int32), ("ahead", C.c_int32), ("xstep", C.c_int32), ("chunks_x", C.c_int32), ("ahead_x", C.c_int32),
+                ("lds_bytes_roll", C.c_int32)]
 
 
 class GmpeError(RuntimeError):

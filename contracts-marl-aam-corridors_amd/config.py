@@ -9,7 +9,7 @@ import math
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NODE_FEATS = 8
 INFO_KEYS = ["individual_reward", "Dist_to_goal", "Time_req_to_goal", "Num_agent_collisions",
              "Num_obst_collisions", "Distance_mean", "Distance_variance", "Mean_by_variance",
@@ -31,6 +31,7 @@ SCENARIOS = {
     "two_phase_graph": SCENARIO_TWO_PHASE,
     "three_phase_graph": SCENARIO_THREE_PHASE,
 }
+FORMATIONS = {"point": 0, "line": 1, "circle": 2}      # gmpe_formation (…_july.py:492-497; custom_scenarios/utils.py:77-130, 165-193, 231-267)
 DYN_DOUBLE_INTEGRATOR, DYN_UNICYCLE, DYN_AIR_TAXI = 0, 1, 2
 DYNAMICS = {"double_integrator": DYN_DOUBLE_INTEGRATOR, "unicycle_vehicle": DYN_UNICYCLE,
             "air_taxi": DYN_AIR_TAXI}
@@ -101,6 +102,7 @@ class GmpeConfig(C.Structure):
         ("walls", GmpeWall * MAX_WALLS),
         ("graph_feat_type", C.c_int32), ("contact_family", C.c_int32),
         ("agent_size", C.c_double), ("collider_size", C.c_double), ("agent_mass", C.c_double), ("action_force_scale", C.c_double),
+        ("formation_type", C.c_int32), ("reserved0", C.c_int32),
     ]
 
     # ---- derived sizes (gmpe_obs_dim / gmpe_num_entities)
@@ -129,9 +131,11 @@ def make_config(scenario_name="nav_metered_one_goal_graph_rotate_tube_july", dyn
                 world_size=4.0, episode_length=25, max_speed=2.0, collision_rew=5.0,
                 formation_rew=1.0, goal_rew=5.0, collaborative=False, total_actions=5, seed=1,
                 env_id_base=0, walls=None, graph_feat_type="relative", contact_family="multiagent", agent_size=None, collider_size=None,
-                agent_mass=1.0, agent_accel=None):
+                agent_mass=1.0, agent_accel=None, formation_type="point"):
     """Build the POD from keyword arguments with the reference's defaults.
 
+    formation_type: 'point' | 'line' | 'circle' — landmark placement at reset of the tube scenarios (…_july.py:492-497; navigation_graph
+    places its goals at random and does not read it).
     graph_feat_type: 'relative' (default) or 'global' (…_july.py:1672-1691; July / navigation_graph only).
     contact_family (navigation_graph only): 'multiagent' = multiagent/core.py:542-548, 872-906 (contact 300 / 0.02, walls 220 / 0.024,
     d_min = COLLISION_DISTANCE, done sides get no agent-agent force) or 'classic' = onpolicy/envs/mpe/core.py:125-130, 273-286
@@ -198,6 +202,9 @@ def make_config(scenario_name="nav_metered_one_goal_graph_rotate_tube_july", dyn
         c.action_force_scale = c.agent_mass * float(agent_accel) if agent_accel is not None else c.agent_mass   # :211-213
         if agent_accel is not None:
             c.sensitivity = float(agent_accel)
+    if formation_type not in FORMATIONS:
+        raise NotImplementedError("formation_type %r (have: %s)" % (formation_type, sorted(FORMATIONS)))
+    c.formation_type = FORMATIONS[formation_type]
     if walls is None:
         walls = default_walls(c.world_size, c.num_walls)
     if len(walls) != c.num_walls or c.num_walls > MAX_WALLS:
@@ -216,8 +223,6 @@ def config_from_args(args, num_envs=None, env_id_base=0):
         raise NotImplementedError("scripted agents are not supported")
     if not g("discrete_action", True):
         raise NotImplementedError("only the discrete action space is supported")
-    if g("formation_type", "point") != "point":
-        raise NotImplementedError("formation_type %r" % g("formation_type"))
     return make_config(
         scenario_name=g("scenario_name"), dynamics_type=g("dynamics_type"),
         num_envs=num_envs if num_envs is not None else g("n_rollout_threads", 1),
@@ -227,7 +232,8 @@ def config_from_args(args, num_envs=None, env_id_base=0):
         max_speed=g("max_speed", 2), collision_rew=g("collision_rew", 5),
         formation_rew=g("formation_rew", 1), goal_rew=g("goal_rew", 5),
         collaborative=g("collaborative", False), total_actions=g("total_actions", 5),
-        seed=g("seed", 1), env_id_base=env_id_base, graph_feat_type=g("graph_feat_type", "relative"))
+        seed=g("seed", 1), env_id_base=env_id_base, graph_feat_type=g("graph_feat_type", "relative"),
+        formation_type=g("formation_type", "point"))
 
 
 # Field table of include/gmpe.h (gmpe_field): name -> (id, dtype, shape-fn(cfg))

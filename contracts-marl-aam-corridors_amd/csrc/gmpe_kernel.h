@@ -359,9 +359,34 @@ __device__ __forceinline__ void reset_world_coop(const KParams& p, const Lds& l,
             }
         }
         if (mine) {
-            const double rel = -ws / 3;
-            const double rx = ca * 0.0 + sa * rel, ry = -sa * 0.0 + ca * rel;
-            for (int q = i; q < L; q += A) { l.ex[A + q] = exx + rx; l.ey[A + q] = exy + ry; }
+            // landmarks by args.formation_type (…_july.py:492-497; rot_inv.py:493-498, two_phase_graph.py:464-469, three_phase_graph.py:459-464);
+            // lane i owns landmarks i, i+A, ... ; the landmarks' reset_velocity() draws nothing
+            if (c.formation_type == GMPE_FORMATION_LINE) {
+                // np.linspace((-ws/2, -ws/2), (ws/2, -ws/2), L) (utils.py:77-130): the zero y step sends BOTH coordinates through linspace's
+                // (i / div) * delta + start branch; the last row is the stop value itself
+                const int div = L - 1;
+                const double s0 = -ws / 2, e0 = ws / 2, ddx = e0 - s0, ddy = s0 - s0;
+                for (int q = i; q < L; q += A) {
+                    const double f = div > 0 ? (double)q / (double)div : (double)q;
+                    double lx = f * ddx + s0, ly = f * ddy + s0;
+                    if (L > 1 && q == L - 1) { lx = e0; ly = s0; }
+                    bool hit = wall_band_hit(p, lx, ly, size);                  // the reference raises ValueError here (utils.py:113-114)
+                    for (int o = 0; o < O; ++o) hit = hit || norm2(l.ex[o0 + o] - lx, l.ey[o0 + o] - ly) < 2.0 * (size + size);
+                    if (hit) err |= 2;
+                    l.ex[A + q] = lx; l.ey[A + q] = ly;
+                }
+            } else if (c.formation_type == GMPE_FORMATION_CIRCLE) {
+                // set_landmarks_in_circle (utils.py:231-267): centre (0, exit_y + ws/5), radius ws/3
+                const double cy = exy + ws / 5, radius = ws / 3, angle_step = 2 * M_PI / L;
+                for (int q = i; q < L; q += A) {
+                    const double ang = q * angle_step;
+                    l.ex[A + q] = 0.0 + radius * cos(ang); l.ey[A + q] = cy + radius * sin(ang);
+                }
+            } else {
+                const double rel = -ws / 3;
+                const double rx = ca * 0.0 + sa * rel, ry = -sa * 0.0 + ca * rel;
+                for (int q = i; q < L; q += A) { l.ex[A + q] = exx + rx; l.ey[A + q] = exy + ry; }
+            }
         }
     } else {
         const double lo = -ws / 2, hi = ws / 2;

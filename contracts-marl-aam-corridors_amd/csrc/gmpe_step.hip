@@ -249,6 +249,7 @@ struct gmpe_handle {
     int rowpairs = 0;                    // rollouts of the exact-size instantiations visit agent-row pairs only (distance_force_pass)
     int nfuse = 0;                       // doubles per env of the separate pair-force buffer (fused rollouts of exact-size navigation_graph tiles), 0: none
     int ramp = -1;                       // GMPE_RAMP, read once by gmpe_create (-1: the default rule of split_pipeline)
+    int rollnt = -1;                     // GMPE_ROLLNT, read once by gmpe_create (-1: nontemporal rollout stores by slot volume)
     unsigned long long* stamps = nullptr;
     hipEvent_t region_ev[2] = {nullptr, nullptr};
     int32_t* edge_ws = nullptr;      // [cap_graphs] counts | [cap_graphs] offsets | [cap_graphs/1024+2] chunk sums
@@ -275,6 +276,10 @@ static void slab_take(char* base, size_t& off, T** p, size_t n, int fill_byte, s
     fills.push_back({off, {bytes, fill_byte}});
     off = (off + bytes + 255) / 256 * 256;
 }
+// The separate pair-force buffer (F2, 2*A*A doubles per env) exists only in launches that can run the fused distance + next-step-force pass: the rollout
+// instantiation k_env<256, 10, SC_NAV, 2> (FUSE_OK in gmpe_kernel.h). Every other launch — step kernels, run-time-size or single-wave rollouts — carves no
+// F2 and is not charged its LDS (the c2 step tile at G = 6 sat 100 bytes under the 48 KiB cut-off because of it).
+static int nfuse_of(const gmpe_handle* h, int block, int ap, int fl) { return (fl == 2 && block > 64 && ap == 10) ? h->nfuse : 0; }
 // scenario variant of a validated config (gmpe_kernel.h)
 static int sc_of(const gmpe_config& c) {
     switch (c.scenario) {
@@ -370,6 +375,8 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     if ((cfg->scenario != GMPE_SCENARIO_NAVIGATION_GRAPH) == (cfg->dynamics == GMPE_DYN_DOUBLE_INTEGRATOR))
         return fail(GMPE_ERR_UNSUPPORTED, "the tube scenarios are kinematic; navigation_graph is double_integrator");
     if (cfg->graph_feat_type < 0 || cfg->graph_feat_type > 1) return fail(GMPE_ERR_UNSUPPORTED, "graph_feat_type: 0 (relative) or 1 (global)");
+    if (cfg->formation_type < GMPE_FORMATION_POINT || cfg->formation_type > GMPE_FORMATION_CIRCLE)
+        return fail(GMPE_ERR_UNSUPPORTED, "formation_type: 0 (point), 1 (line) or 2 (circle)");
     if (cfg->contact_family < 0 || cfg->contact_family > 1 || (cfg->contact_family == 1 && (cfg->scenario != GMPE_SCENARIO_NAVIGATION_GRAPH || !(cfg->agent_mass > 0))))
         return fail(GMPE_ERR_UNSUPPORTED, "contact_family 1 (classic MPE) applies to navigation_graph and needs agent_mass > 0");
     if (cfg->dynamics == GMPE_DYN_DOUBLE_INTEGRATOR ? (cfg->n_actions != 5 && cfg->n_actions != 9) : cfg->n_actions != 25)
@@ -428,7 +435,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     if (getenv("GMPE_FUSE") && atoi(getenv("GMPE_FUSE")) == 0) h->nfuse = 0;
     h->rowpairs = (getenv("GMPE_FUSE") && atoi(getenv("GMPE_FUSE")) == 0) ? 0 : 1;
     int Gmax = 64 / h->A; if (Gmax < 1) Gmax = 1; if (Gmax > (int)N) Gmax = (int)N;
-    while (Gmax > 1 && lds_bytes(Gmax, h->A, E, h->D, cfg->num_walls, h->nfuse) > 48 * 1024) --Gmax;
+    while (Gmax > 1 && lds_bytes(Gmax, h->A, E, h->D, cfg->num_walls, h->nfuse) > 48 * 1024) --Gmax;   // one cap for both tile shapes (the rollout tile carries the F2 buffer)
     int ap_sel = (h->A == h->L && h->O == 0 && (h->A == 10 || h->A == 3)) ? h->A : 0;   // exact-size instantiations of the common cases (A = L, no obstacles)
     if (getenv("GMPE_AP") && atoi(getenv("GMPE_AP")) == 0) ap_sel = 0;                    // tuning: run-time sizes
     h->ap = ap_sel;
@@ -440,7 +447,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
         for (int bi = 0; bi < 3 && !G; ++bi)
             for (int g = G0; g <= Gmax; ++g) {
                 const size_t tiles = (N + g - 1) / g;
-                const int per_cu = sc_dispatch_occ(sc_of(h->c), blocks[bi], ap_sel, lds_bytes(g, h->A, E, h->D, cfg->num_walls, h->nfuse));
+                const int per_cu = sc_dispatch_occ(sc_of(h->c), blocks[bi], ap_sel, lds_bytes(g, h->A, E, h->D, cfg->num_walls, 0));
                 if (per_cu > 0 && tiles <= (size_t)per_cu * dev_cus) { G = g; block_sel = blocks[bi]; break; }
             }
     }
@@ -467,7 +474,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
             if (G0 < 1) G0 = 1;
             for (int g = G0; g <= Gmax && !Gr; ++g) {
                 const size_t tiles = (N + g - 1) / g;
-                const int per_cu = sc_dispatch_occ(sc_of(h->c), h->block_roll, ap_sel, lds_bytes(g, h->A, E, h->D, cfg->num_walls, h->nfuse), 1);
+                const int per_cu = sc_dispatch_occ(sc_of(h->c), h->block_roll, ap_sel, lds_bytes(g, h->A, E, h->D, cfg->num_walls, nfuse_of(h, h->block_roll, ap_sel, 2)), 1);
                 if (per_cu > 0 && tiles <= (size_t)per_cu * dev_cus) Gr = g;
             }
         }
@@ -491,12 +498,13 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
         // adjacency is >= ~95 % of the bytes (A >= 48): c5 shapes (64 agents) 2048 envs 1515 us split vs 1731 fused, 4096: 2994 vs 3455,
         // 8192: 6043 vs 6565, 16384: 11618 vs 12981 (with the run-ahead bound below); c4 (A = 32) 1260 vs 1132: stays fused
         // (profiles/r02_notes.md). Everything else runs the fused kernel.
-        const size_t tiles_resident = (size_t)dev_cus * (size_t)[&] { const int q = sc_dispatch_occ(sc_of(h->c), block_sel ? block_sel : 256, ap_sel, lds_bytes(G, h->A, E, h->D, cfg->num_walls, h->nfuse)); return q > 0 ? q : 1; }();
+        const size_t tiles_resident = (size_t)dev_cus * (size_t)[&] { const int q = sc_dispatch_occ(sc_of(h->c), block_sel ? block_sel : 256, ap_sel, lds_bytes(G, h->A, E, h->D, cfg->num_walls, 0)); return q > 0 ? q : 1; }();
         const size_t tiles_total = (N + G - 1) / G;
         h->split = getenv("GMPE_SPLIT") ? atoi(getenv("GMPE_SPLIT"))
                                         : (out_bytes > 192.0 * 1024 * 1024 && h->A >= 48 ? 1 : 0);
         if ((uint64_t)N * E * E >= (1ull << 32)) h->split = 0;            // k_adj_expand indexes the compact matrix with 32 bits
         h->roll = getenv("GMPE_ROLL") ? atoi(getenv("GMPE_ROLL")) : 1;
+        h->rollnt = getenv("GMPE_ROLLNT") ? (atoi(getenv("GMPE_ROLLNT")) != 0) : -1;
         if ((uint64_t)h->A * E * E / 4 * (E * E / 4 + 1) >= (1ull << 32)) h->split = 0;   // k_adj_expand's exact magic division
         if (h->split) {
             void* q = nullptr;
@@ -553,7 +561,8 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
     // Multi-wave tiles specialise (wave 0: reward / info / write-back, waves 1..: graph stores). Measured with the final register
     // budgets: C2 30.2 vs 33.2 us, C4 1286 vs 1297 us, C5 shard 1901 vs 1970 us — on everywhere (GMPE_SPEC=0 turns it off).
     h->spec = getenv("GMPE_SPEC") ? atoi(getenv("GMPE_SPEC")) : 1;
-    const size_t lds = lds_bytes(h->G > h->G_roll ? h->G : h->G_roll, h->A, E, h->D, cfg->num_walls, h->nfuse);
+    const size_t lds_step = lds_bytes(h->G, h->A, E, h->D, cfg->num_walls, 0), lds_roll = lds_bytes(h->G_roll, h->A, E, h->D, cfg->num_walls, nfuse_of(h, h->block_roll, h->ap, 2));
+    const size_t lds = lds_step > lds_roll ? lds_step : lds_roll;
     if (lds > 160 * 1024) { gmpe_destroy(h); return fail(GMPE_ERR_UNSUPPORTED, "per-tile LDS exceeds 160 KiB"); }
     if (lds > 48 * 1024) {                                   // opt in to >64 KiB dynamic LDS (gfx950: 160 KiB per CU)
         const hipError_t e = sc_dispatch_lds(sc_of(h->c), (int)lds);
@@ -655,7 +664,7 @@ static void fill_params(const gmpe_handle* h, KParams& p, int G) {
     p.A = h->A; p.L = h->L; p.O = h->O; p.E = h->E; p.D = h->D; p.F = h->F; p.G = G;
     p.ablate = h->ablate;
     p.nt = h->nt;
-    p.nfuse = h->nfuse; p.rowpairs = h->rowpairs;
+    p.nfuse = 0; p.rowpairs = h->rowpairs;                                // nfuse: set per launch by dispatch_env
     p.spec = h->spec;
     p.stamps = h->stamps;
     p.K = 1; p.S = 1; p.num_slots = 1;
@@ -670,8 +679,9 @@ static void fill_params(const gmpe_handle* h, KParams& p, int G) {
     p.m_FW = magic_of(p.A * (p.A - 1) / 2 + p.A * p.O);
 }
 static int ap_of(const gmpe_handle* h) { return h->ap; }
-static void dispatch_env(const gmpe_handle* h, int block, int ap, int fl, hipStream_t st, const KParams& p) {
-    const size_t lds = lds_bytes(p.G, h->A, h->E, h->D, h->c.num_walls, h->nfuse);
+static void dispatch_env(const gmpe_handle* h, int block, int ap, int fl, hipStream_t st, KParams& p) {
+    p.nfuse = nfuse_of(h, block, ap, fl);
+    const size_t lds = lds_bytes(p.G, h->A, h->E, h->D, h->c.num_walls, p.nfuse);
     const dim3 grid((p.env_hi - p.env_lo + p.G - 1) / p.G);
     switch (sc_of(h->c)) {
         case SC_NAV: launch_env<SC_NAV>(block, ap, fl, grid, lds, st, p); break;
@@ -792,7 +802,7 @@ int gmpe_rollout_steps(gmpe_handle* h, const int32_t* actions_dev, const gmpe_ro
     p.masks = r->masks; p.active = r->active_masks;
     {   // a rollout that fills more slots than the 256 MiB Infinity Cache holds streams past it: nontemporal graph stores (like the big launches)
         const double step_bytes = (double)h->c.num_envs * h->A * ((double)h->E * h->E * (p.o.adj_compact ? 1.0 / h->A : 1.0) + (double)h->F * h->E) * 4.0;
-        p.nt = getenv("GMPE_ROLLNT") ? atoi(getenv("GMPE_ROLLNT")) : (step_bytes * r->num_slots > 192.0 * 1024 * 1024 ? 1 : 0);
+        p.nt = h->rollnt >= 0 ? h->rollnt : (step_bytes * r->num_slots > 192.0 * 1024 * 1024 ? 1 : 0);      // GMPE_ROLLNT was read by gmpe_create: no getenv on the collect path
     }
     HIPCHK(hipSetDevice(h->device));
     dispatch_env(h, h->block_roll, ap_of(h), 2, static_cast<hipStream_t>(stream), p);
@@ -804,7 +814,8 @@ int gmpe_get_tuning(const gmpe_handle* h, gmpe_tuning* t) {
     if (!h || !t) return fail(GMPE_ERR_INVALID_ARG, "gmpe_get_tuning: null argument");
     memset(t, 0, sizeof *t);
     t->G = h->G; t->block = h->block; t->nt = h->nt; t->spec = h->spec; t->split = h->split; t->roll = h->roll; t->ap = ap_of(h);
-    t->lds_bytes = (int32_t)lds_bytes(h->G, h->A, h->E, h->D, h->c.num_walls, h->nfuse);
+    t->lds_bytes = (int32_t)lds_bytes(h->G, h->A, h->E, h->D, h->c.num_walls, 0);
+    t->lds_bytes_roll = (int32_t)lds_bytes(h->G_roll, h->A, h->E, h->D, h->c.num_walls, nfuse_of(h, h->block_roll, h->ap, 2));
     t->G_roll = h->G_roll; t->block_roll = h->block_roll;
     t->chunks = h->split ? h->chunks : 0; t->ahead = h->split ? h->ahead : 0;
     t->xstep = h->split ? h->xstep : 0; t->chunks_x = h->split ? h->chunks_x : 0; t->ahead_x = h->split ? h->ahead_x : 0;

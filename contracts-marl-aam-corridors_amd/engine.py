@@ -287,6 +287,13 @@ class GmpeEngine(object):
             dummy = torch.empty((2,), dtype=torch.int64, device=self.device)
             cap = run(dummy, dummy, 0)
         cap = int(cap if cap is not None else N * copies * E * E)
+        if cap == 0:
+            # an empty edge set is a valid answer (max_edge_dist = 0, or every node masked): zero-size tensors have a null data_ptr the C ABI would
+            # reject as a missing argument, so count with a one-element scratch and hand back empty tensors
+            dummy = torch.empty((2,), dtype=torch.int64, device=self.device)
+            m = run(dummy, dummy, 0)
+            return (torch.empty((2, 0), dtype=torch.int64 if index64 else torch.int32, device=self.device),
+                    torch.empty((0,), dtype=torch.float32, device=self.device), m)
         ei = torch.empty((2, cap), dtype=torch.int64 if index64 else torch.int32, device=self.device)
         ea = torch.empty((cap,), dtype=torch.float32, device=self.device)
         m = run(ei, ea, cap)

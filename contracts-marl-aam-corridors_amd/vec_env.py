@@ -109,6 +109,7 @@ class BatchedGraphMPEVecEnv(object):
         self.share_agent_id_observation_space = [Box(-np.inf, np.inf, (A * 1,), f32) for _ in range(A)]
         self.waiting = False
         self._pending = None
+        self._errors_reported = False
         # info rows: two device buffers bound alternately (a LazyInfos keeps a reference to its step's buffer instead of a per-step clone);
         # sticky device error flags (tape exhausted / placement gave up) travel down with every hand-off and raise GmpeError here
         o = self.engine.out
@@ -164,6 +165,7 @@ class BatchedGraphMPEVecEnv(object):
     def _raise_errors(self):
         """Sticky per-env error flags of the engine (include/gmpe.h error_flags) -> GmpeError. The reference has no counterpart: its
         rejection sampler spins forever in a world too small for its agents (…_july.py:462-486), the engine's is bounded."""
+        self._errors_reported = True                  # close() will not raise the same sticky flags again
         self.engine.check_errors()
 
     # ------------------------------------------------------------------ GraphSubprocVecEnv surface
@@ -250,10 +252,19 @@ class BatchedGraphMPEVecEnv(object):
         raise NotImplementedError("rendering (pyglet viewer) is out of scope of the step engine")
 
     def close(self):
+        """Frees the handle unconditionally. Sticky device errors that no reset / step hand-off has raised yet are raised here — once: a close() in a
+        `finally` / `except` clean-up path after a GmpeError must not replace the exception that is already propagating (it warns instead)."""
         if self.closed:
             return
         try:
-            self.engine.check_errors()                # last chance to report sticky device errors (synchronises)
+            if not self._errors_reported:
+                self.engine.check_errors()            # last chance to report sticky device errors (synchronises)
+        except _lib.GmpeError:
+            self._errors_reported = True
+            raise
+        except Exception as e:                        # a handle that is already in a failed state: do not mask the original failure
+            import warnings
+            warnings.warn("BatchedGraphMPEVecEnv.close: could not read the device error flags (%s)" % e)
         finally:
             self.engine.close()
             self.closed = True
@@ -272,11 +283,15 @@ class BatchedGraphMPEVecEnv(object):
                                   "(seed, env id), the counterpart of env.seed(seed + rank*1000) in train_mpe.py:31")
 
 
-def make_train_env(all_args, device=0):
-    """Counterpart of onpolicy/scripts/train_mpe.py:21-43 for env_name == 'GraphMPE' (n_rollout_threads == 1 -> the GraphDummyVecEnv shape)."""
+def make_train_env(all_args, device=0, eval_surface=False):
+    """Counterpart of onpolicy/scripts/train_mpe.py:21-43 for env_name == 'GraphMPE'. `step` returns the GraphSubprocVecEnv 7-tuple for EVERY thread
+    count, one included: that is what the collect / eval loops unpack (graph_mpe_runner.py:83, 490). The reference itself builds GraphDummyVecEnv
+    for n_rollout_threads == 1 (train_mpe.py:34-36), whose 8-tuple (env_wrappers.py:920-936) those loops cannot unpack — a single-thread training
+    run of the reference raises "too many values to unpack"; only GMPERunner.render wants the 8-tuple (graph_mpe_runner.py:621-622). Pass
+    eval_surface=True (or use make_eval_env) to get that shape."""
     if getattr(all_args, "env_name", "GraphMPE") != "GraphMPE":
         raise NotImplementedError("only the GraphMPE route is built")
-    return BatchedGraphMPEVecEnv(all_args, num_envs=all_args.n_rollout_threads, device=device, eval_surface=(all_args.n_rollout_threads == 1))
+    return BatchedGraphMPEVecEnv(all_args, num_envs=all_args.n_rollout_threads, device=device, eval_surface=eval_surface)
 
 
 def GraphMPEEnv(args, device=0):

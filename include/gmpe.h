@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GMPE_ABI_VERSION 2
+#define GMPE_ABI_VERSION 3
 #define GMPE_NODE_FEATS 8          /* …_july.py:1771  [rel_vel2, rel_pos2, rel_goal2, occupied, type]; rot_inv: 7 (gmpe_node_feats) */
 #define GMPE_INFO_KEYS 18          /* …_july.py:806-828 + 'individual_reward' (environment.py:1048) + 'Phase_reached' (rot_inv:835) */
 #define GMPE_MAX_AGENTS 64         /* one wavefront lane per agent in the sequential-semantics pass   */
@@ -68,6 +68,14 @@ typedef enum gmpe_dynamics {
     GMPE_DYN_UNICYCLE = 1,              /* kinematic, UnicycleVehicleConfig constants                 */
     GMPE_DYN_AIR_TAXI = 2               /* kinematic: core.py:231-340, 819-826                        */
 } gmpe_dynamics;
+
+/* args.formation_type (…_july.py:192, 492-497): where random_scenario puts the landmarks (goal i belongs to agent i). */
+typedef enum gmpe_formation {
+    GMPE_FORMATION_POINT = 0,           /* set_landmarks_in_point (custom_scenarios/utils.py:165-193): all at exit + R(angle) @ [0, -ws/3]      */
+    GMPE_FORMATION_LINE = 1,            /* set_landmarks_in_line (utils.py:77-130) called with start (-ws/2, -ws/2), end (ws/2, -ws/2):
+                                           np.linspace(start, end, L) — the zero y-step takes linspace's (i / div) * delta branch             */
+    GMPE_FORMATION_CIRCLE = 2           /* set_landmarks_in_circle (utils.py:231-267): centre (0, exit_y + ws/5), radius ws/3, angle i * 2 pi / L */
+} gmpe_formation;
 
 typedef struct gmpe_wall {              /* multiagent/core.py:354-373 Wall                             */
     int32_t orient;                     /* 0 = 'H' (lies along x at y = axis_pos), 1 = 'V'            */
@@ -120,6 +128,10 @@ typedef struct gmpe_config {
     double agent_size, collider_size;   /* classic: Entity.size of agents / of obstacles (mpe/core.py:44)                          */
     double agent_mass;                  /* Entity.mass (mpe/core.py:52 initial_mass = 1.0): v += F / mass * dt                     */
     double action_force_scale;          /* apply_action_force (mpe/core.py:205-214): mass * accel if accel is not None else mass   */
+    /* ---- ABI 3 ---- */
+    int32_t formation_type;             /* gmpe_formation: landmark placement of the tube scenarios' reset (…_july.py:492-497, rot_inv.py:493-498,
+                                           two_phase_graph.py:464-469, three_phase_graph.py:459-464); navigation_graph does not read it        */
+    int32_t reserved0;
 } gmpe_config;
 
 /* Persistent per-env state, addressable for checkpoint / parity injection. */
@@ -319,12 +331,13 @@ typedef struct gmpe_tuning {
                                       k_adj_expand materialises the A ego copies                           */
     int32_t roll;               /* 1: gmpe_step_many runs the persistent rollout kernel                    */
     int32_t ap;                 /* exact-size instantiation (0: run-time sizes)                            */
-    int32_t lds_bytes;          /* dynamic LDS per tile                                                    */
+    int32_t lds_bytes;          /* dynamic LDS per tile of the step kernels                                */
     int32_t diag_build;         /* 1: library built with -DGMPE_DIAG (ablations honoured): never for results */
     int32_t G_roll, block_roll; /* tile shape of the rollout kernel (its own register budget, hence its own residency)  */
     int32_t chunks, ahead;      /* split path: env chunks per step; how many chunks the fused kernel may run ahead of the expansion (0: unbounded) */
     int32_t xstep;              /* split path: gmpe_step_many chains the steps' chunk pipelines (no join between open-loop steps)          */
     int32_t chunks_x, ahead_x;  /* ... with this chunking / run-ahead bound                                                                */
+    int32_t lds_bytes_roll;     /* dynamic LDS per tile of the rollout kernel (G_roll envs; + the pair-force buffer of fused navigation_graph rollouts)     */
 } gmpe_tuning;
 int gmpe_get_tuning(const gmpe_handle* h, gmpe_tuning* out);
 

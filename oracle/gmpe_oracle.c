@@ -110,6 +110,7 @@ int gmpo_num_entities(const gmpe_config* c) { return c->num_agents + c->num_land
 
 int gmpo_create(const gmpe_config* cfg, gmpo** out) {
     if (!cfg || !out || cfg->abi_version != GMPE_ABI_VERSION) { snprintf(g_err, sizeof g_err, "bad config/abi"); return GMPE_ERR_INVALID_ARG; }
+    if (cfg->formation_type < GMPE_FORMATION_POINT || cfg->formation_type > GMPE_FORMATION_CIRCLE) { snprintf(g_err, sizeof g_err, "bad formation_type"); return GMPE_ERR_UNSUPPORTED; }
     if (cfg->num_agents < 1 || cfg->num_agents > GMPE_MAX_AGENTS || cfg->num_landmarks < cfg->num_agents ||
         cfg->num_envs < 1 || cfg->num_walls > GMPE_MAX_WALLS || gmpo_num_entities(cfg) > GMPE_MAX_ENTITIES) {
         snprintf(g_err, sizeof g_err, "config out of range"); return GMPE_ERR_INVALID_ARG;
@@ -850,10 +851,35 @@ static void reset_world_july(envv* v) {
         v->status[k] = 0;
         ++k; tries = 0;
     }
-    /* set_landmarks_in_point (utils.py:165-193): every landmark at exit + R(angle) @ [0, -ws/3] */
-    const double rel = -ws / 3;
-    const double rx = ca * 0.0 + sa * rel, ry = -sa * 0.0 + ca * rel;
-    for (int l = 0; l < v->L; ++l) { v->lm[2 * l] = exx + rx; v->lm[2 * l + 1] = exy + ry; }
+    /* landmarks by args.formation_type (…_july.py:492-497; the same call sites in rot_inv.py:493-498, two_phase_graph.py:464-469,
+     * three_phase_graph.py:459-464). The landmarks' reset_velocity() draws nothing (DoubleIntegratorXYState, core.py:400). */
+    if (c->formation_type == GMPE_FORMATION_LINE) {
+        /* set_landmarks_in_line(start = (-ws/2, -ws/2), end = (ws/2, -ws/2)) -> np.linspace(start, end, L) (utils.py:77-130). The y step is 0, so
+         * linspace takes its "any_step_zero" branch for BOTH coordinates: y = (i / div) * delta + start, last row = stop exactly; L = 1: start. */
+        const int num = v->L, div = num - 1;
+        const double sx0 = -ws / 2, sy0 = -ws / 2, ex0 = ws / 2, ey0 = -ws / 2;
+        const double ddx = ex0 - sx0, ddy = ey0 - sy0;
+        for (int l = 0; l < num; ++l) {
+            const double f = div > 0 ? (double)l / (double)div : (double)l;
+            double lx = f * ddx + sx0, ly = f * ddy + sy0;
+            if (num > 1 && l == num - 1) { lx = ex0; ly = ey0; }
+            if (is_obstacle_collision(v, lx, ly, size)) h->error_flags[n] |= 2;     /* the reference raises ValueError (utils.py:113-114) */
+            v->lm[2 * l] = lx; v->lm[2 * l + 1] = ly;
+        }
+    } else if (c->formation_type == GMPE_FORMATION_CIRCLE) {
+        /* set_landmarks_in_circle(center = (0, exit_y + ws/5), radius = ws/3) (utils.py:231-267) */
+        const double cx = 0.0, cy = exy + ws / 5, radius = ws / 3;
+        const double angle_step = 2 * M_PI / v->L;
+        for (int l = 0; l < v->L; ++l) {
+            const double ang = l * angle_step;
+            v->lm[2 * l] = cx + radius * cos(ang); v->lm[2 * l + 1] = cy + radius * sin(ang);
+        }
+    } else {
+        /* set_landmarks_in_point (utils.py:165-193): every landmark at exit + R(angle) @ [0, -ws/3] */
+        const double rel = -ws / 3;
+        const double rx = ca * 0.0 + sa * rel, ry = -sa * 0.0 + ca * rel;
+        for (int l = 0; l < v->L; ++l) { v->lm[2 * l] = exx + rx; v->lm[2 * l + 1] = exy + ry; }
+    }
     min_times(v);
 }
 /* navigation_graph reset — this project's own composition: uniform placement in

@@ -5,6 +5,7 @@
 Vectors (data only — inputs and the reference's outputs):
   rotinv_A{3,6,10}_s{seed}.npz  the same for nav_graph_metered_single_corridor_rot_inv (float32 obs, 7 node features).
   julyglobal_A{3,6}_s{seed}.npz  the July rollouts with graph_feat_type='global' (7 node features in world coordinates).
+  {july,rotinv,twophase,threephase}{line,circle}_A*_s{seed}_guided.npz  guided rollouts with formation_type 'line' / 'circle' (distinct landmarks).
   july_A{3,10}_s{seed}.npz   end-to-end rollouts of MultiAgentGraphEnv (July tube scenario, air_taxi),
                              driven like graphworker does (env_wrappers.py:851-873: step, auto-reset
                              when all agents are done), with the uniform-sample tape that replays the
@@ -82,10 +83,10 @@ def _guided_action(w, sc, rng, w_opt, a_opt):
 
 
 def july_rollout(num_agents, seed, T, world_size=4.0, episode_length=25, guided=False,
-                 scenario_name="nav_metered_one_goal_graph_rotate_tube_july", graph_feat_type="relative"):
+                 scenario_name="nav_metered_one_goal_graph_rotate_tube_july", graph_feat_type="relative", formation_type="point"):
     np.random.seed(seed)
     args = H.july_args(num_agents, world_size=world_size, episode_length=episode_length, scenario_name=scenario_name,
-                       graph_feat_type=graph_feat_type)
+                       graph_feat_type=graph_feat_type, formation_type=formation_type)
     info_keys = INFO_KEYS + (["Phase_reached"] if ("rot_inv" in scenario_name or "phase_graph" in scenario_name) else [])
     with H.UniformTape() as tape:
         env, sc, w = H.make_july_env(args)
@@ -96,7 +97,7 @@ def july_rollout(num_agents, seed, T, world_size=4.0, episode_length=25, guided=
         out = {"A": A, "E": E, "T": T, "seed": seed, "world_size": world_size,
                "episode_length": episode_length, "collision_rew": args.collision_rew,
                "formation_rew": args.formation_rew, "goal_rew": args.goal_rew,
-               "max_speed": args.max_speed, "init_prev_phase": pre["prev_phase"]}
+               "max_speed": args.max_speed, "init_prev_phase": pre["prev_phase"], "formation_type": formation_type}
         tape.samples.clear()
         o, ids, nd, ad = env.reset(0)
         assert all(a is ad[0] for a in ad)
@@ -378,6 +379,34 @@ def main_global(scenario_name="nav_metered_one_goal_graph_rotate_tube_july", pre
               "steps with a done agent", int(d["st_status"].any(axis=1).sum()), "phase_reached", d["st_phase_reached"].max(axis=0))
 
 
+def main_formation():
+    # formation_type 'line' / 'circle' (…_july.py:492-495 -> custom_scenarios/utils.py:77-130, 231-267; the same call sites in the rot_inv family's
+    # files): DISTINCT landmark positions, so the landmark x landmark adjacency block, per-agent goals, landmark masks on distinct rows and
+    # info_callback's nearest-landmark logic are pinned against the reference in their general form ('point' makes every landmark coincide).
+    # Guided rollouts: the agents fly gate -> tube -> exit -> their OWN landmark.
+    JULY = "nav_metered_one_goal_graph_rotate_tube_july"
+    jobs = [(JULY, "july", "line", 3, 2, 130, 2.0, 60), (JULY, "july", "line", 6, 4, 140, 3.0, 70),
+            (JULY, "july", "circle", 3, 2, 130, 2.0, 60), (JULY, "july", "circle", 6, 4, 140, 3.0, 70),
+            ("nav_graph_metered_single_corridor_rot_inv", "rotinv", "line", 4, 80, 130, 2.4, 60),
+            ("nav_graph_metered_single_corridor_rot_inv", "rotinv", "circle", 6, 84, 140, 3.0, 70),
+            ("three_phase_graph", "threephase", "line", 3, 90, 130, 2.0, 60), ("three_phase_graph", "threephase", "circle", 5, 94, 140, 3.0, 70),
+            ("two_phase_graph", "twophase", "line", 3, 100, 90, 2.0, 45)]
+    for name, prefix, form, A, seed, T, ws, el in jobs:
+        seed -= 1
+        while True:                                   # the reference crashes at construction for some seeds (see main_rot)
+            seed += 1
+            try:
+                d = july_rollout(A, seed, T, world_size=ws, episode_length=el, guided=True, scenario_name=name, formation_type=form)
+                break
+            except AttributeError as e:
+                print("seed", seed, "reference crashed:", str(e)[:70])
+        p = os.path.join(HERE, "%s%s_A%d_s%d_guided.npz" % (prefix, form, A, seed))
+        np.savez_compressed(p, **d)
+        lm = d["reset0_landmarks"]
+        print(p, os.path.getsize(p), "resets", int(d["did_reset"].sum()), "agents that reached their goal", d["st_status"].max(axis=0).astype(int),
+              "goal_tracker", d["st_goal_tracker"].max(axis=0), "distinct landmarks", len({tuple(np.round(q, 9)) for q in lm}))
+
+
 def main_blocks():
     np.savez_compressed(os.path.join(HERE, "rk45_airtaxi.npz"), **rk45_fixture())
     np.savez_compressed(os.path.join(HERE, "force_classic.npz"), **force_classic_fixture())
@@ -388,7 +417,7 @@ def main_blocks():
 def main(which):
     """`python make_fixtures.py [july|rot|phase|blocks ...]` regenerates the named groups (default: all)."""
     H.selfcheck_uniform_patch()
-    which = which or ["july", "global", "globalrot", "rot", "phase", "blocks"]
+    which = which or ["july", "global", "globalrot", "rot", "phase", "formation", "blocks"]
     if "july" in which:
         main_july()
     if "global" in which:
@@ -401,6 +430,8 @@ def main(which):
     if "phase" in which:
         main_rot("two_phase_graph", "twophase", seed=20, phase_col=14)
         main_rot("three_phase_graph", "threephase", seed=40, phase_col=14)
+    if "formation" in which:
+        main_formation()
     if "blocks" in which:
         main_blocks()
     print("done")

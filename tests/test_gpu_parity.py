@@ -16,7 +16,8 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-JULY = [q for pre in ("july", "julyglobal", "rotinv", "twophase", "threephase", "rotinvglobal", "twophaseglobal") for q in sorted(glob.glob(os.path.join(GOLD, pre + "_A*_s*.npz")))]
+JULY = [q for pre in ("july", "julyglobal", "rotinv", "twophase", "threephase", "rotinvglobal", "twophaseglobal",
+                       "julyline", "julycircle", "rotinvline", "rotinvcircle", "twophaseline", "threephaseline", "threephasecircle") for q in sorted(glob.glob(os.path.join(GOLD, pre + "_A*_s*.npz")))]
 ROT = "nav_graph_metered_single_corridor_rot_inv"
 ROTFAM = [ROT, "two_phase_graph", "three_phase_graph"]
 TOL = 1e-5
@@ -44,7 +45,8 @@ def _july_cfg(d, scenario_name="nav_metered_one_goal_graph_rotate_tube_july", **
                             num_envs=1, num_agents=int(d["A"]), world_size=float(d["world_size"]),
                             episode_length=int(d["episode_length"]), max_speed=float(d["max_speed"]),
                             collision_rew=float(d["collision_rew"]), formation_rew=float(d["formation_rew"]),
-                            goal_rew=float(d["goal_rew"]), graph_feat_type=str(d["graph_feat_type"]) if "graph_feat_type" in d else "relative", **kw)
+                            goal_rew=float(d["goal_rew"]), graph_feat_type=str(d["graph_feat_type"]) if "graph_feat_type" in d else "relative",
+                            formation_type=str(d["formation_type"]) if "formation_type" in d else "point", **kw)
 
 
 @pytest.mark.parametrize("path", JULY, ids=[os.path.basename(p)[:-4] for p in JULY])
@@ -527,6 +529,11 @@ def test_edges_from_compact_adjacency_equal_materialised(scen, A, O):
             assert torch.equal(ci.to(torch.int32), ei) and torch.equal(ca, ea)
         if m == 0:
             continue
+        # an empty edge set is a result, not an error: threshold 0 -> no edge; explicit cap = 0 -> count only
+        zi, za, zm = eng.edges_from_adj_compact(compact, A, 0.0)
+        assert zm == 0 and tuple(zi.shape) == (2, 0) and tuple(za.shape) == (0,)
+        zi, za, zm = eng.edges_from_adj_compact(compact, A, dist, inclusive=incl, cap=0)
+        assert zm == m and tuple(zi.shape) == (2, 0)
         cap = max(1, m // 3)
         ci, ca, cm = eng.edges_from_adj_compact(compact, A, dist, inclusive=incl, cap=cap)
         assert cm == m and ci.shape[1] == cap

@@ -51,6 +51,8 @@ def _draw(k):
         knobs["SPEC"] = 0
     if r.rand() < 0.2:
         knobs["ROLLNT"] = 1
+    if scen != "navigation_graph" and r.rand() < 0.4:                     # drawn last: the earlier draws of every k stay what they were in round 3
+        kw["formation_type"] = str(r.choice(["line", "circle"]))            # distinct landmarks (…_july.py:492-495)
     return kw, knobs
 
 

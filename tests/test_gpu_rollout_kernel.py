@@ -45,11 +45,13 @@ CASES = [
     dict(scenario_name=ROTFAM[2], num_envs=18, num_agents=10, world_size=4.0, episode_length=8, seed=76),
     dict(scenario_name="navigation_graph", num_envs=5, num_agents=32, num_obstacles=8, num_walls=4, world_size=8.0, episode_length=4, seed=77),
     dict(scenario_name=JULY, num_envs=3, num_agents=64, world_size=30.0, episode_length=3, seed=78),
+    dict(scenario_name=JULY, num_envs=29, num_agents=10, world_size=4.0, episode_length=7, seed=79, formation_type="line"),       # distinct landmarks: the cached
+    dict(scenario_name=ROTFAM[0], num_envs=29, num_agents=10, world_size=4.0, episode_length=7, seed=80, formation_type="circle"),  # landmark block of rollouts
 ]
 
 
 @pytest.mark.parametrize("shape", [None, (2, 64), (3, 256), (6, 256)], ids=["auto", "G2-B64", "G3-B256", "G6-B256"])
-@pytest.mark.parametrize("kw", CASES, ids=["%s-A%d-O%d" % (c["scenario_name"][:10], c["num_agents"], c.get("num_obstacles", 0)) for c in CASES])
+@pytest.mark.parametrize("kw", CASES, ids=["%s-A%d-O%d%s" % (c["scenario_name"][:10], c["num_agents"], c.get("num_obstacles", 0), "-" + c["formation_type"] if "formation_type" in c else "") for c in CASES])
 def test_rollout_kernel_equals_step_loop(monkeypatch, kw, shape):
     import torch
     if shape:
@@ -284,3 +286,77 @@ def test_fused_force_pass_with_goals_reached_mid_rollout(monkeypatch, fuse):
     _compare_state(e1, e2, "after fused rollout")
     assert e2.tuning()["ap"] == 10
     e1.check_errors(); e2.check_errors()
+
+
+def _bench_shape_rollout(kw, n_envs, n_slice, K, n_slots):
+    """The launch bench.py times (bench.py run_k_steps, `rollout` mode with slots): eng.rollout(actions, K, slot0 = slot 0 of [n_slots, ...] storage for every
+    output, strides = one slot) — NO masks, first_slot 0, the nontemporal path chosen by slot volume. Every surviving slot (the last n_slots steps) of the first
+    n_slice envs is compared with the oracle, then the final state and the RNG counters."""
+    import torch
+    from gmpe.engine import StepOutputs
+    cfg = gmpe.make_config(num_envs=n_envs, **kw)
+    eng, orc = _engine(cfg), ol.Oracle(gmpe.make_config(num_envs=n_slice, **kw))
+    eng.reset(); orc.reset()
+    A, E = cfg.num_agents, cfg.num_entities
+    g = torch.Generator(device="cuda"); g.manual_seed(42)
+    acts = torch.randint(0, cfg.n_actions, (K, n_envs, A), generator=g, device="cuda", dtype=torch.int32)
+    o = eng.out
+    slots = {k: torch.empty((n_slots,) + tuple(getattr(o, k).shape), dtype=getattr(o, k).dtype, device="cuda") for k in OUT_KEYS}
+    step_bytes = sum(getattr(o, k).numel() * getattr(o, k).element_size() for k in OUT_KEYS)
+    assert step_bytes * n_slots > (256 << 20)                      # past the Infinity Cache: gmpe_rollout_steps takes the nontemporal store path (gmpe_step.hip, by slot volume)
+    eng.rollout(acts, K, slot0=StepOutputs(**{k: v[0] for k, v in slots.items()}), num_slots=n_slots, strides={k: v[0].numel() for k, v in slots.items()})
+    torch.cuda.synchronize()
+    a = acts[:, :n_slice].cpu().numpy()
+    n_resets = 0
+    for k in range(K):
+        oo = orc.step(a[k])
+        n_resets += int(oo[7].sum())
+        if k < K - n_slots:
+            continue                                               # overwritten by step k + n_slots (the slots wrap)
+        s = k % n_slots
+        lab = "step %d slot %d" % (k, s)
+        np.testing.assert_allclose(_np(slots["obs"][s][:n_slice]), oo[0], rtol=0, atol=TOL, err_msg=lab + " obs")
+        np.testing.assert_allclose(_np(slots["node_obs"][s][:n_slice]), oo[2], rtol=0, atol=TOL, err_msg=lab + " node")
+        adj = _np(slots["adj"][s][:n_slice])
+        ref = np.broadcast_to(oo[3][:, None], adj.shape)
+        np.testing.assert_allclose(adj, ref, rtol=0, atol=TOL, err_msg=lab + " adj")
+        np.testing.assert_array_equal(adj == 0, ref == 0, err_msg=lab + " adj mask")
+        np.testing.assert_allclose(_np(slots["reward"][s][:n_slice]), oo[4], rtol=6e-8, atol=TOL, err_msg=lab + " rew")
+        np.testing.assert_array_equal(_np(slots["done"][s][:n_slice]).astype(bool), oo[5], err_msg=lab + " done")
+        np.testing.assert_array_equal(_np(slots["agent_id"][s][:n_slice])[..., 0], oo[1][..., 0], err_msg=lab + " ids")
+        np.testing.assert_allclose(_np(slots["info"][s][:n_slice]), oo[6], rtol=2e-6, atol=2e-5, err_msg=lab + " info")
+    from test_gpu_parity import STATE_F, STATE_I
+    for f in STATE_F + ["tube", "landmarks", "obstacles", "goal_min_time", "delta_spacing", "prev_proj"]:
+        np.testing.assert_allclose(eng.get(f)[:n_slice], orc.get(f), rtol=0, atol=1e-9, err_msg="final " + f)
+    for f in STATE_I:
+        np.testing.assert_array_equal(eng.get(f)[:n_slice], orc.get(f), err_msg="final " + f)
+    # all envs, not only the slice: the slots' adjacency is symmetric, zero-diagonal and one matrix per env in every surviving slot
+    for s in range(min(n_slots, 3)):
+        adj = slots["adj"][s]
+        assert torch.equal(adj, adj.transpose(-1, -2)) and torch.equal(adj, adj[:, :1].expand_as(adj))
+    eng.check_errors()
+    return eng, n_resets
+
+
+@pytest.mark.parametrize("scen", ["navigation_graph", JULY], ids=["c2", "c3"])
+def test_timed_launch_shape_full_size_26_slots_vs_oracle(scen):
+    """the EXACT launch the driver's bench line is timed on — 4096 x 10, one rollout launch into slot-per-step storage [26, ...]
+    (2.5 GB: nontemporal, output-order adjacency stores), K = 60 so the slots wrap twice — against a 512-env oracle slice in every surviving slot."""
+    eng, n_resets = _bench_shape_rollout(dict(scenario_name=scen, num_agents=10, world_size=4.0, episode_length=25, seed=1234), 4096, 512, 60, 26)
+    assert n_resets >= 2 * 512                                     # two all-env reset steps inside the launch
+    assert eng.tuning()["ap"] == 10 and eng.tuning()["roll"] == 1
+
+
+def test_timed_launch_shape_c4_slots_vs_oracle():
+    """The c4 line's launch (bench.py --workload c4): 8192 envs x (32 agents + 8 obstacles + 4 walls), rollout into as many slots as the bench's memory rule
+    allows (26 x 6.1 GB = 158 GB where it fits), slots wrapping; a 64-env oracle slice in every surviving slot."""
+    import torch
+    kw = dict(scenario_name="navigation_graph", num_agents=32, num_obstacles=8, num_walls=4, world_size=8.0, episode_length=25, seed=1234)
+    cfg = gmpe.make_config(num_envs=8192, **kw)
+    A, E = 32, 72
+    step_bytes = 8192 * (A * 13 * 4 + A * 4 + A * E * 8 * 4 + A * E * E * 4 + A * 4 + A + A * 18 * 4)
+    budget = min(int(torch.cuda.mem_get_info()[0] * 0.75), 200 << 30)       # bench.py's rule
+    n_slots = 26 if step_bytes * 26 <= budget else int(max(4, budget // step_bytes))
+    K = n_slots + 4
+    eng, n_resets = _bench_shape_rollout(kw, 8192, 64, K, n_slots)
+    assert n_resets >= 64

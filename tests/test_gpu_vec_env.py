@@ -159,10 +159,15 @@ def test_too_small_world_raises_through_the_drop_in():
     envs2.engine.reset()                                    # engine-level reset: no host check
     with pytest.raises(GmpeError, match="placement gave up"):
         envs2.step(np.zeros((8, 8), dtype=np.int64))
-    with pytest.raises(GmpeError):
-        envs2.close()
+    envs2.close()                                           # already reported by step(): a close() in a clean-up path must not raise it again
     assert envs2.closed
-    envs.closed = True; envs.engine.close()
+    envs.close()                                            # reported by reset()
+    assert envs.closed
+    envs3 = BatchedGraphMPEVecEnv(a, num_envs=8)
+    envs3.engine.reset()                                    # nobody has seen the flags yet: close() is the last hand-off and raises them once
+    with pytest.raises(GmpeError, match="placement gave up"):
+        envs3.close()
+    assert envs3.closed
 
 
 @pytest.mark.parametrize("pinned", [True, False])
@@ -204,7 +209,11 @@ def test_eval_surface_eight_tuple_with_reset_count():
         counts.append(reset_count)
     assert counts == [0, 0, 0, 1, 0, 0, 0, 1, 0]
     envs.close()
-    tr = make_train_env(a)                                  # one rollout thread: the reference builds GraphDummyVecEnv here too
+    tr = make_train_env(a)                                  # one rollout thread: the collect loop unpacks 7 values (graph_mpe_runner.py:83) — the 8-tuple is opt-in
+    tr.reset()
+    assert len(tr.step(np.zeros((1, 4), dtype=np.int64))) == 7
+    tr.close()
+    tr = make_train_env(a, eval_surface=True)
     tr.reset()
     assert len(tr.step(np.zeros((1, 4), dtype=np.int64))) == 8
     tr.close()

@@ -30,6 +30,22 @@ def test_global_graph_features_vs_oracle(kw):
     assert _rollout_vs_oracle(cfg, 26, seed=7) >= kw["num_envs"]
 
 
+@pytest.mark.parametrize("form", ["line", "circle"])
+@pytest.mark.parametrize("scen", [JULY, "nav_graph_metered_single_corridor_rot_inv", "two_phase_graph", "three_phase_graph"])
+def test_formation_line_circle_vs_oracle(scen, form):
+    """formation_type 'line' / 'circle' (…_july.py:492-495 -> custom_scenarios/utils.py:77-130, 231-267): distinct landmark positions through the
+    in-kernel reset; exact-size (A = 10) and run-time-size (A = 4, more landmarks than agents) tiles, auto-resets included. The oracle's placement is pinned by
+    the reference's own line / circle rollouts (tests/golden/*line*, *circle*), which test_golden_replay_on_gpu also replays on the GPU."""
+    cfg = gmpe.make_config(scenario_name=scen, formation_type=form, num_envs=45, num_agents=10, world_size=4.0, episode_length=8, seed=131)
+    assert cfg.formation_type == {"line": 1, "circle": 2}[form]
+    assert _rollout_vs_oracle(cfg, 20, seed=11) >= 45
+    cfg = gmpe.make_config(scenario_name=scen, formation_type=form, num_envs=19, num_agents=4, num_landmarks=6, world_size=2.4, episode_length=40, seed=132)
+    _rollout_vs_oracle(cfg, 45, seed=12, shrink_world=True)
+    lm = ol.Oracle(cfg); lm.reset()
+    pts = lm.get("landmarks")[0]
+    assert len({tuple(np.round(q, 9)) for q in pts}) == 6                  # distinct positions
+
+
 def test_global_graph_features_are_ego_independent_except_redrawn_velocities():
     import torch
     cfg = gmpe.make_config(scenario_name=JULY, graph_feat_type="global", num_envs=64, num_agents=5, seed=9)

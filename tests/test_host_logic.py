@@ -58,6 +58,7 @@ def test_config_pod_layout_matches_c_header():
       printf("%d %d\n", (int)GMPE_F_ERROR_FLAGS, (int)GMPE_F_COUNT);
       printf("%zu %zu %zu %zu %zu\n", offsetof(gmpe_config, graph_feat_type), offsetof(gmpe_config, agent_size), offsetof(gmpe_config, action_force_scale),
              sizeof(gmpe_rollout), sizeof(gmpe_tuning));
+      printf("%zu\n", offsetof(gmpe_config, formation_type));
       return 0; }'''
     with tempfile.TemporaryDirectory() as td:
         cpath = os.path.join(td, "t.c")
@@ -74,6 +75,7 @@ def test_config_pod_layout_matches_c_header():
     from gmpe._lib import GmpeRollout, GmpeTuning
     assert [int(x) for x in out[10:15]] == [G.graph_feat_type.offset, G.agent_size.offset, G.action_force_scale.offset,
                                             C.sizeof(GmpeRollout), C.sizeof(GmpeTuning)]
+    assert int(out[15]) == G.formation_type.offset                       # ABI 3
 
 
 def test_create_without_gpu_fails_loudly():
@@ -133,6 +135,14 @@ def test_config_from_args_mirrors_reference_fields():
     a.graph_feat_type = "global"
     cg = gmpe.config_from_args(a)
     assert cg.graph_feat_type == 1 and cg.node_feats == 7 and gcfg.algorithmic_bytes_per_env_step(cg) == 24250 - 4 * 10 * 20
+    # formation_type 'line' / 'circle' (…_july.py:492-495) reach the POD; anything else raises like the reference's commented-out branch
+    for name, code in (("point", 0), ("line", 1), ("circle", 2)):
+        a.formation_type = name
+        assert gmpe.config_from_args(a).formation_type == code
+    a.formation_type = "random"
+    with pytest.raises(NotImplementedError):
+        gmpe.config_from_args(a)
+    a.formation_type = "point"
     a.graph_feat_type = "relative"
     a.scenario_name = "two_phase_graph"
     a.graph_feat_type = "global"                             # the rot_inv family has the same _get_entity_feat_global (rot_inv.py:1668-1687)
