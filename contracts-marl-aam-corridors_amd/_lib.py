@@ -15,13 +15,14 @@ SYMBOLS = ["gmpe_abi_version", "gmpe_last_error", "gmpe_obs_dim", "gmpe_node_fea
            "gmpe_field_bytes", "gmpe_get_field", "gmpe_set_field", "gmpe_edges_from_adj", "gmpe_masks_from_dones",
            "gmpe_timing_enable", "gmpe_timing_read", "gmpe_timing_mark", "gmpe_timing_region_ms",
            "gmpe_rollout_steps", "gmpe_get_tuning", "gmpe_step_many_launches", "gmpe_edges_from_adj_compact",
-           "gmpe_set_control_override", "gmpe_field_device_ptr", "gmpe_step_envs", "gmpe_step_many_envs"]
+           "gmpe_set_control_override", "gmpe_field_device_ptr", "gmpe_step_envs", "gmpe_step_many_envs",
+           "gmpe_entity_table_width", "gmpe_expand_node_obs"]
 
 
 class GmpeOutputs(C.Structure):
     _fields_ = [("obs", C.c_void_p), ("agent_id", C.c_void_p), ("node_obs", C.c_void_p),
                 ("adj", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),
-                ("info", C.c_void_p), ("adj_compact", C.c_int32), ("reserved", C.c_int32)]
+                ("info", C.c_void_p), ("adj_compact", C.c_int32), ("reserved", C.c_int32), ("entity_table", C.c_void_p)]
 
 
 class GmpeRollout(C.Structure):
@@ -29,7 +30,7 @@ class GmpeRollout(C.Structure):
     _fields_ = [("num_steps", C.c_int32), ("num_action_sets", C.c_int32), ("num_slots", C.c_int32), ("first_slot", C.c_int32),
                 ("stride_obs", C.c_int64), ("stride_agent_id", C.c_int64), ("stride_node_obs", C.c_int64), ("stride_adj", C.c_int64),
                 ("stride_reward", C.c_int64), ("stride_done", C.c_int64), ("stride_info", C.c_int64), ("stride_masks", C.c_int64),
-                ("masks", C.c_void_p), ("active_masks", C.c_void_p)]
+                ("masks", C.c_void_p), ("active_masks", C.c_void_p), ("stride_entity_table", C.c_int64)]
 
 
 class GmpeTuning(C.Structure):
@@ -84,6 +85,8 @@ def load():
     lib.gmpe_timing_region_ms.argtypes = [P, C.POINTER(C.c_double)]
     lib.gmpe_rollout_steps.argtypes = [P, P, C.POINTER(GmpeRollout), C.POINTER(GmpeOutputs), P]
     lib.gmpe_get_tuning.argtypes = [P, C.POINTER(GmpeTuning)]
+    lib.gmpe_entity_table_width.argtypes = [C.POINTER(GmpeConfig)]
+    lib.gmpe_expand_node_obs.argtypes = [C.POINTER(GmpeConfig), I, P, C.c_int64, C.c_int64, P, C.c_int64, C.c_int64, P]
     from .config import ABI_VERSION
     if lib.gmpe_abi_version() != ABI_VERSION:
         raise GmpeError("libgmpe.so ABI version mismatch")

@@ -115,6 +115,12 @@ class GmpeConfig(C.Structure):
         return 19 if self.scenario == SCENARIO_TUBE_JULY else (15 if self.scenario in (SCENARIO_TWO_PHASE, SCENARIO_THREE_PHASE) else 13)
 
     @property
+    def entity_table_width(self):
+        """gmpe_entity_table_width: doubles per env of the entity table (x[E], y[E], vox / voy / vnx / vny [A], + cos / sin [A] rot_inv family, + exit two_phase)."""
+        return (2 * self.num_entities + 4 * self.num_agents + (2 * self.num_agents if self.scenario in ROT_FAMILY else 0)
+                + (2 if self.scenario == SCENARIO_TWO_PHASE else 0))
+
+    @property
     def node_feats(self):
         return 7 if (self.scenario in ROT_FAMILY or self.graph_feat_type == 1) else NODE_FEATS
 

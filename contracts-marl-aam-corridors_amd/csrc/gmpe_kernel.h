@@ -45,7 +45,8 @@ struct KParams {
     // rollout (FL == 2 instantiations, gmpe_rollout_steps): K steps inside one launch, state carried in LDS / registers
     int K, S;                 // steps, action sets (step k reads action set k % S of act [S,N,A])
     int num_slots, first_slot;   // outputs of step k go to slot (first_slot + k) % num_slots
-    long long st_obs, st_id, st_node, st_adj, st_rew, st_done, st_info, st_mask;   // slot strides in elements
+    long long st_obs, st_id, st_node, st_adj, st_rew, st_done, st_info, st_mask, st_tab;   // slot strides in elements
+    int TW; uint32_t m_TW;    // doubles per env of the entity table output (gmpe_entity_table_width) and its division magic
     float* masks;             // optional [slots][N,A] GraphReplayBuffer masks / active_masks of the step (graph_buffer.py:223-251)
     float* active;
     // magic multipliers for exact unsigned division by run-time constants (q < 2^22): floor(q/d) = umulhi(q, m)
@@ -304,6 +305,8 @@ __device__ __forceinline__ double win_draw(const KParams& p, double* buf, int64_
 // (profiles/README.md): a chain of ~300-cycle fp64 sqrt per placed entity and attempt on a single lane.
 // All lanes of wave 0 call this (wave-uniform); `mine` = lane belongs to an env that resets. Writes positions / headings to LDS
 // (ex, ey, n2, n3, tube) and landmark / obstacle / tube records to HBM.
+// (Round 4 tried computing the NEXT episode's placement ahead of the reset — exact, since a reset is a pure function of the env's draw counter — on wave 3 of a
+// steady rollout step: the second copy of this loop in the step loop cost more registers than the shorter reset step gave back; profiles/r04_placement_ahead_experiment.patch.)
 template <int SC>
 __device__ __forceinline__ void reset_world_coop(const KParams& p, const Lds& l, int n, int i, bool mine, unsigned long long emask, int64_t& ctr, int& err) {
     const gmpe_config& c = p.c;
@@ -669,6 +672,24 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
     }
     
     STAMP_T(16, 64); STAMP_T(19, 192);                                     // diagnostic build: adjacency part issued (waves 1 / 3)
+    if (o.entity_table) {
+        // entity table (include/gmpe.h gmpe_outputs.entity_table): the fp64 per-entity state every node_obs row below is a pure function of — what a rank ships
+        // to the learner instead of the [A,E,F] rows (gmpe_expand_node_obs rebuilds them there bit for bit)
+        const int W = p.TW;
+        double* dst = o.entity_table + (size_t)n0 * W;
+        for (int q = t0; q < Gv * W; q += nthr) {
+            const int gg = fdiv(q, W, p.m_TW), w = q - gg * W;
+            if (!l.flags[gg * 4 + 3]) continue;
+            double val;
+            if (w < 2 * E) val = w < E ? l.ex[gg * E + w] : l.ey[gg * E + (w - E)];
+            else if (SC == SC_TWO && w >= W - 2) val = l.tube[gg * GMPE_TUBE_STRIDE + (w == W - 2 ? T_EXX : T_EXY)];
+            else {
+                const int r = w - 2 * E, blk = fdiv(r, A, p.m_A), a = gg * A + (r - blk * A);
+                val = blk == 0 ? l.vox[a] : blk == 1 ? l.voy[a] : blk == 2 ? l.vnx[a] : blk == 3 ? l.vny[a] : blk == 4 ? l.cn[a] : l.sn[a];
+            }
+            dst[q] = val;
+        }
+    }
     if (sc_rotfam(SC) && o.node_obs && !(abl & 2) && p.c.graph_feat_type != 1) {
         // rot_inv node row (…rot_inv.py:1690-1766): 7 float32 = [rel_vel, rel_pos, rel_goal (all rotated by the ego heading), type].
         // Positions / velocities are rounded to float32 FIRST, differenced in float32, rotated in float64, rounded again.
@@ -943,6 +964,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
             if (out_k.reward) out_k.reward += (size_t)slot * p.st_rew;
             if (out_k.done) out_k.done += (size_t)slot * p.st_done;
             if (out_k.info) out_k.info += (size_t)slot * p.st_info;
+            if (out_k.entity_table) out_k.entity_table += (size_t)slot * p.st_tab;
             const int anext = aset + 1 == p.S ? 0 : aset + 1;
             if (ag && kk + 1 < K) act_next = p.act[(size_t)anext * N * A + na];
             aset = anext;

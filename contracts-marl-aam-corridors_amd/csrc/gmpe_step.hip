@@ -311,7 +311,84 @@ static hipError_t sc_dispatch_lds(int sc, int lds) {
     }
 }
 
+// ---------------------------------------------------------------- learner side: node_obs rows from entity tables (gmpe_expand_node_obs)
+// One thread per (env-step b, ego i, entity k). The arithmetic repeats stream_graph_fn's three row variants operation for operation (this translation unit
+// is compiled with the same -ffp-contract=off), so the rows are bit-identical to what the engine writes: tests/test_gpu_gather.py compares them for every scenario x
+// feature type. KIND 0: relative, F = 8 (…_july.py:1694-1771); 1: rot_inv family, F = 7 (rot_inv.py:1690-1766; two: goal = corridor exit, two_phase_graph.py:1405);
+// 2: graph_feat_type 'global', F = 7 (…_july.py:1672-1691).
+template <int KIND>
+__global__ __launch_bounds__(256) void k_node_expand(const double* __restrict__ tab, float* __restrict__ out, long long total, int A, int L, int E, int W, int two,
+                                                     long long n_in, long long n_out, long long off) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int k = (int)(t % E);
+    const long long r1 = t / E;
+    const int ei = (int)(r1 % A);
+    const long long b = r1 / A;                                          // env-step index in the table: block * n_in + env
+    const long long blk = b / n_in, n = b - blk * n_in;
+    const double* T = tab + (size_t)b * W;
+    const double* ex = T; const double* ey = T + E;
+    const double* vox = T + 2 * E; const double* voy = vox + A; const double* vnx = voy + A; const double* vny = vnx + A;
+    const bool kag = k < A;
+    const int kk = kag ? k : 0;
+    const bool post = k <= ei;                                           // agent k's re-drawn velocity is visible to ego ei iff k <= ei (ordered-visibility rule)
+    const float typ = kag ? 0.0f : (k < A + L ? 1.0f : 2.0f);
+    const size_t row = ((size_t)(blk * n_out + off + n) * A + ei) * E + k;
+    if (KIND == 0) {
+        const double kx = ex[k], ky = ey[k];
+        const double kvox = kag ? vox[kk] : 0.0, kvoy = kag ? voy[kk] : 0.0, kvnx = kag ? vnx[kk] : 0.0, kvny = kag ? vny[kk] : 0.0;
+        const double gx = kag ? ex[A + kk] : kx, gy = kag ? ey[A + kk] : ky;
+        const double px = ex[ei], py = ey[ei], evx = vnx[ei], evy = vny[ei];
+        float4* d = reinterpret_cast<float4*>(out + row * 8);
+        d[0] = make_float4((float)((post ? kvnx : kvox) - evx), (float)((post ? kvny : kvoy) - evy), (float)(kx - px), (float)(ky - py));
+        d[1] = make_float4((float)(gx - px), (float)(gy - py), kag ? 0.0f : 1.0f, typ);
+    } else if (KIND == 1) {
+        const double* cn = vny + A; const double* sn = cn + A;
+        const float kx = (float)ex[k], ky = (float)ey[k];
+        const float kvox = kag ? (float)vox[kk] : 0.0f, kvoy = kag ? (float)voy[kk] : 0.0f, kvnx = kag ? (float)vnx[kk] : 0.0f, kvny = kag ? (float)vny[kk] : 0.0f;
+        const float gxk = two ? (float)T[W - 2] : (kag ? (float)ex[A + kk] : 0.0f), gyk = two ? (float)T[W - 1] : (kag ? (float)ey[A + kk] : 0.0f);
+        const float apx = (float)ex[ei], apy = (float)ey[ei], avx = (float)vnx[ei], avy = (float)vny[ei];
+        const double cs = cn[ei], s_ = sn[ei];
+        const float rvx = (post ? kvnx : kvox) - avx, rvy = (post ? kvny : kvoy) - avy;
+        const float rpx = kx - apx, rpy = ky - apy;
+        double o0, o1, o2, o3, o4, o5;
+        rot2(cs, s_, (double)rvx, (double)rvy, o0, o1);
+        rot2(cs, s_, (double)rpx, (double)rpy, o2, o3);
+        if (kag) rot2(cs, s_, (double)(gxk - apx), (double)(gyk - apy), o4, o5); else { o4 = o2; o5 = o3; }
+        float* d = out + row * 7;
+        d[0] = (float)o0; d[1] = (float)o1; d[2] = (float)o2; d[3] = (float)o3; d[4] = (float)o4; d[5] = (float)o5; d[6] = typ;
+    } else {
+        const float kx = (float)ex[k], ky = (float)ey[k];
+        const float kvox = kag ? (float)vox[kk] : 0.0f, kvoy = kag ? (float)voy[kk] : 0.0f, kvnx = kag ? (float)vnx[kk] : 0.0f, kvny = kag ? (float)vny[kk] : 0.0f;
+        const float gx = kag ? (float)ex[A + kk] : kx, gy = kag ? (float)ey[A + kk] : ky;
+        float* d = out + row * 7;
+        d[0] = post ? kvnx : kvox; d[1] = post ? kvny : kvoy; d[2] = kx; d[3] = ky; d[4] = gx; d[5] = gy; d[6] = typ;
+    }
+}
+
 extern "C" {
+
+int gmpe_expand_node_obs(const gmpe_config* cfg, int device, const double* table_dev, int64_t num_blocks, int64_t envs_per_block,
+                         float* node_obs_dev, int64_t out_envs_per_block, int64_t out_env_offset, void* stream) {
+    if (!cfg || !table_dev || !node_obs_dev) return fail(GMPE_ERR_INVALID_ARG, "gmpe_expand_node_obs: null argument");
+    if (cfg->abi_version != GMPE_ABI_VERSION) return fail(GMPE_ERR_INVALID_ARG, "gmpe_config.abi_version mismatch");
+    if (num_blocks < 0 || envs_per_block < 1 || out_env_offset < 0 || out_env_offset + envs_per_block > out_envs_per_block)
+        return fail(GMPE_ERR_INVALID_ARG, "gmpe_expand_node_obs: the block's envs do not fit the output's env range");
+    if (num_blocks == 0) return GMPE_OK;
+    const int A = cfg->num_agents, L = cfg->num_landmarks, E = gmpe_num_entities(cfg), W = gmpe_entity_table_width(cfg);
+    if (A < 1 || A > GMPE_MAX_AGENTS || L < A || E > GMPE_MAX_ENTITIES) return fail(GMPE_ERR_INVALID_ARG, "gmpe_expand_node_obs: config out of range");
+    HIPCHK(hipSetDevice(device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long total = (long long)num_blocks * envs_per_block * A * E;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if ((total + 255) / 256 > 0x7fffffffLL) return fail(GMPE_ERR_INVALID_ARG, "gmpe_expand_node_obs: too many rows for one launch (split the blocks)");
+    const int two = cfg->scenario == GMPE_SCENARIO_TWO_PHASE;
+    if (cfg->graph_feat_type == 1) hipLaunchKernelGGL((k_node_expand<2>), grid, dim3(256), 0, st, table_dev, node_obs_dev, total, A, L, E, W, two, (long long)envs_per_block, (long long)out_envs_per_block, (long long)out_env_offset);
+    else if (cfg->scenario >= GMPE_SCENARIO_ROT_INV) hipLaunchKernelGGL((k_node_expand<1>), grid, dim3(256), 0, st, table_dev, node_obs_dev, total, A, L, E, W, two, (long long)envs_per_block, (long long)out_envs_per_block, (long long)out_env_offset);
+    else hipLaunchKernelGGL((k_node_expand<0>), grid, dim3(256), 0, st, table_dev, node_obs_dev, total, A, L, E, W, two, (long long)envs_per_block, (long long)out_envs_per_block, (long long)out_env_offset);
+    HIPCHK(hipGetLastError());
+    return GMPE_OK;
+}
 
 int gmpe_abi_version(void) { return GMPE_ABI_VERSION; }
 const char* gmpe_last_error(void) { return g_err.c_str(); }
@@ -324,6 +401,9 @@ int gmpe_obs_dim(const gmpe_config* c) {
 }
 int gmpe_node_feats(const gmpe_config* c) { return (c->scenario >= GMPE_SCENARIO_ROT_INV || c->graph_feat_type == 1) ? 7 : GMPE_NODE_FEATS; }
 int gmpe_num_entities(const gmpe_config* c) { return c->num_agents + c->num_landmarks + c->num_obstacles; }
+int gmpe_entity_table_width(const gmpe_config* c) {
+    return 2 * gmpe_num_entities(c) + 4 * c->num_agents + (c->scenario >= GMPE_SCENARIO_ROT_INV ? 2 * c->num_agents : 0) + (c->scenario == GMPE_SCENARIO_TWO_PHASE ? 2 : 0);
+}
 
 static int field_info(const gmpe_handle* h, int f, void** ptr, size_t* bytes) {
     const size_t N = h->c.num_envs, NA = N * h->A;
@@ -677,6 +757,7 @@ static void fill_params(const gmpe_handle* h, KParams& p, int G) {
     p.m_AC = magic_of(p.A * (p.A + p.O)); p.m_AEE = magic_of(p.A * p.E * p.E);
     p.m_W = magic_of(p.E * (p.E - 1) / 2); p.m_Sx = magic_of((p.E & 1) ? (p.E - 1) / 2 : p.E - 1);      // distance_pass: pairs per env, inner divisor
     p.m_FW = magic_of(p.A * (p.A - 1) / 2 + p.A * p.O);
+    p.TW = gmpe_entity_table_width(&h->c); p.m_TW = magic_of(p.TW);
 }
 static int ap_of(const gmpe_handle* h) { return h->ap; }
 static void dispatch_env(const gmpe_handle* h, int block, int ap, int fl, hipStream_t st, KParams& p) {
@@ -798,7 +879,7 @@ int gmpe_rollout_steps(gmpe_handle* h, const int32_t* actions_dev, const gmpe_ro
     p.act = actions_dev; p.mode = MODE_STEP;
     p.K = r->num_steps; p.S = r->num_action_sets; p.num_slots = r->num_slots; p.first_slot = r->first_slot;
     p.st_obs = r->stride_obs; p.st_id = r->stride_agent_id; p.st_node = r->stride_node_obs; p.st_adj = r->stride_adj;
-    p.st_rew = r->stride_reward; p.st_done = r->stride_done; p.st_info = r->stride_info; p.st_mask = r->stride_masks;
+    p.st_rew = r->stride_reward; p.st_done = r->stride_done; p.st_info = r->stride_info; p.st_mask = r->stride_masks; p.st_tab = r->stride_entity_table;
     p.masks = r->masks; p.active = r->active_masks;
     {   // a rollout that fills more slots than the 256 MiB Infinity Cache holds streams past it: nontemporal graph stores (like the big launches)
         const double step_bytes = (double)h->c.num_envs * h->A * ((double)h->E * h->E * (p.o.adj_compact ? 1.0 / h->A : 1.0) + (double)h->F * h->E) * 4.0;
@@ -869,7 +950,7 @@ int gmpe_step_many_envs(gmpe_handle* h, const int32_t* actions_dev, int32_t num_
 }
 static bool same_out(const gmpe_outputs& a, const gmpe_outputs& b) {
     return a.obs == b.obs && a.agent_id == b.agent_id && a.node_obs == b.node_obs && a.adj == b.adj && a.reward == b.reward &&
-           a.done == b.done && a.info == b.info && a.adj_compact == b.adj_compact;
+           a.done == b.done && a.info == b.info && a.adj_compact == b.adj_compact && a.entity_table == b.entity_table;
 }
 static int find_graph(const gmpe_handle* h, const int32_t* actions_dev, int32_t K, int32_t S, const gmpe_outputs& o) {
     for (size_t q = 0; q < h->graphs.size(); ++q) {

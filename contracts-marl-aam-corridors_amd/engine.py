@@ -14,7 +14,7 @@ from .config import FIELDS, INFO_KEYS, NODE_FEATS, GmpeConfig, algorithmic_bytes
 
 class StepOutputs(object):
     """Device-resident outputs of one step/reset (torch tensors on the engine's device)."""
-    __slots__ = ("obs", "agent_id", "node_obs", "adj", "reward", "done", "info")
+    __slots__ = ("obs", "agent_id", "node_obs", "adj", "reward", "done", "info", "entity_table")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -22,7 +22,10 @@ class StepOutputs(object):
 
 
 class GmpeEngine(object):
-    def __init__(self, cfg, device=0, adj_compact=False, with_info=True):
+    def __init__(self, cfg, device=0, adj_compact=False, with_info=True, node_form="rows"):
+        """node_form: "rows" — the engine writes node_obs [N,A,E,F] (what GraphSubprocVecEnv hands the runner); "table" — it writes the fp64 entity table
+        [N,W] instead (include/gmpe.h gmpe_outputs.entity_table: the state the rows are a pure function of, ~8x fewer bytes — the form a rank ships to the learner,
+        expanded there by expand_node_obs); "both" — both outputs."""
         if not isinstance(cfg, GmpeConfig):
             raise TypeError("cfg must be a gmpe.config.GmpeConfig")
         self.lib = _lib.load()
@@ -33,6 +36,9 @@ class GmpeEngine(object):
         self.N, self.A = cfg.num_envs, cfg.num_agents
         self.E, self.D = cfg.num_entities, cfg.obs_dim
         self.adj_compact = bool(adj_compact)
+        if node_form not in ("rows", "table", "both"):
+            raise ValueError("node_form must be 'rows', 'table' or 'both'")
+        self.node_form = node_form
         self.h = C.c_void_p()
         _lib.check(self.lib.gmpe_create(C.byref(cfg), self.device.index, C.byref(self.h)), "gmpe_create")
         N, A, E, D = self.N, self.A, self.E, self.D
@@ -40,7 +46,8 @@ class GmpeEngine(object):
         self.out = StepOutputs(
             obs=torch.empty((N, A, D), dtype=torch.float32, device=dev),
             agent_id=torch.empty((N, A, 1), dtype=torch.int32, device=dev),
-            node_obs=torch.empty((N, A, E, cfg.node_feats), dtype=torch.float32, device=dev),
+            node_obs=torch.empty((N, A, E, cfg.node_feats), dtype=torch.float32, device=dev) if node_form != "table" else None,
+            entity_table=torch.empty((N, cfg.entity_table_width), dtype=torch.float64, device=dev) if node_form != "rows" else None,
             adj=torch.empty((N, E, E) if adj_compact else (N, A, E, E), dtype=torch.float32, device=dev),
             reward=torch.empty((N, A), dtype=torch.float32, device=dev),
             done=torch.empty((N, A), dtype=torch.uint8, device=dev),
@@ -53,7 +60,7 @@ class GmpeEngine(object):
     def _pack(self, o):
         p = lambda t: None if t is None else t.data_ptr()
         return _lib.GmpeOutputs(p(o.obs), p(o.agent_id), p(o.node_obs), p(o.adj), p(o.reward), p(o.done),
-                                p(o.info), int(self.adj_compact), 0)
+                                p(o.info), int(self.adj_compact), 0, p(o.entity_table))
 
     def rebind(self, outputs):
         """Point the engine at other caller-owned output tensors (same shapes/dtypes, same device)."""
@@ -152,7 +159,8 @@ class GmpeEngine(object):
         r = _lib.GmpeRollout(int(num_steps), int(a.shape[0]), int(num_slots), int(first_slot),
                              int(st.get("obs", 0)), int(st.get("agent_id", 0)), int(st.get("node_obs", 0)), int(st.get("adj", 0)),
                              int(st.get("reward", 0)), int(st.get("done", 0)), int(st.get("info", 0)), int(st.get("masks", 0)),
-                             None if masks is None else masks.data_ptr(), None if active_masks is None else active_masks.data_ptr())
+                             None if masks is None else masks.data_ptr(), None if active_masks is None else active_masks.data_ptr(),
+                             int(st.get("entity_table", 0)))
         _lib.check(self.lib.gmpe_rollout_steps(self.h, a.data_ptr(), C.byref(r), C.byref(o), self._stream()), "gmpe_rollout_steps")
         return self.out
 
@@ -299,6 +307,10 @@ class GmpeEngine(object):
         m = run(ei, ea, cap)
         return ei[:, :min(m, cap)], ea[:min(m, cap)], m
 
+    def expand_node_obs(self, table, out=None, out_envs=None, env_offset=0):
+        """node_obs rows from entity tables, bit-identical to what the engine writes (gmpe_expand_node_obs; module-level `expand_node_obs` needs no engine)."""
+        return expand_node_obs(self.cfg, table, out=out, out_envs=out_envs, env_offset=env_offset)
+
     def masks_from_dones(self, done, masks, active_masks):
         """masks / active_masks (f32 [N,A,...], contiguous, N*A elements) from a uint8 [N,A] done tensor, one tiny kernel."""
         _lib.check(self.lib.gmpe_masks_from_dones(self.h, done.data_ptr(), masks.data_ptr() if masks is not None else None,
@@ -326,3 +338,25 @@ class GmpeEngine(object):
     @property
     def bytes_per_env_step(self):
         return algorithmic_bytes_per_env_step(self.cfg)
+
+
+def expand_node_obs(cfg, table, out=None, out_envs=None, env_offset=0):
+    """Learner side of the compact gather: float64 entity tables [..., n, W] (device tensor, contiguous; leading dims = blocks such as the T+1 slots of a rollout) ->
+    node_obs float32 [..., out_envs, A, E, F], rows of the table's n envs written at env_offset .. env_offset + n of every block (default: out_envs = n). The rows are
+    bit-identical to the engine's own node_obs (same arithmetic, gmpe_step.hip k_node_expand). No handle needed: the learner rank may own no envs."""
+    lib = _lib.load()
+    if table.dtype != torch.float64 or not table.is_contiguous() or not table.is_cuda or table.dim() < 2 or table.shape[-1] != cfg.entity_table_width:
+        raise ValueError("table must be a contiguous float64 device tensor [..., n, %d]" % cfg.entity_table_width)
+    n = int(table.shape[-2])
+    blocks = int(table.numel() // (n * table.shape[-1])) if n else 0
+    out_envs = n if out_envs is None else int(out_envs)
+    A, E, F = cfg.num_agents, cfg.num_entities, cfg.node_feats
+    shape = tuple(table.shape[:-2]) + (out_envs, A, E, F)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=table.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != table.device:
+        raise ValueError("out must be a contiguous float32 tensor of shape %s on %s" % (shape, table.device))
+    if blocks and n:
+        _lib.check(lib.gmpe_expand_node_obs(C.byref(cfg), table.device.index, table.data_ptr(), blocks, n, out.data_ptr(), out_envs, int(env_offset),
+                                            C.c_void_p(torch.cuda.current_stream(table.device).cuda_stream)), "gmpe_expand_node_obs")
+    return out

@@ -14,26 +14,61 @@ from .config import NODE_FEATS
 from .engine import StepOutputs
 
 
+def storage_spec(cfg, episode_length, adj_compact, node_form):
+    """name -> (dtype, shape) of the env-side arrays of a rollout (graph_buffer.py:84-164 shapes). With node_form "table" the node features are kept as the fp64
+    entity table [T+1, N, W] they are a pure function of (include/gmpe.h gmpe_outputs.entity_table) instead of the [T+1, N, A, E, F] rows."""
+    N, A, E, D = cfg.num_envs, cfg.num_agents, cfg.num_entities, cfg.obs_dim
+    T, T1 = int(episode_length), int(episode_length) + 1
+    f32 = torch.float32
+    spec = {"obs": (f32, (T1, N, A, D))}
+    if node_form != "table":
+        spec["node_obs"] = (f32, (T1, N, A, E, cfg.node_feats))
+    if node_form != "rows":
+        spec["entity_table"] = (torch.float64, (T1, N, cfg.entity_table_width))
+    spec["_adj"] = (f32, (T1, N, E, E) if adj_compact else (T1, N, A, E, E))
+    spec["agent_id"] = (torch.int32, (T1, N, A, 1))
+    spec["rewards"] = (f32, (T, N, A, 1))
+    spec["dones"] = (torch.uint8, (T, N, A))
+    spec["masks"] = (f32, (T1, N, A, 1))
+    spec["active_masks"] = (f32, (T1, N, A, 1))
+    return spec
+
+
 class DeviceRolloutBuffer(object):
-    def __init__(self, engine, episode_length, use_centralized_V=True):
+    def __init__(self, engine, episode_length, use_centralized_V=True, storage=None):
+        """storage: optional dict name -> caller-owned tensor for some or all of the arrays of storage_spec (e.g. views of ONE byte slab that a collective ships
+        as a whole, sharding.ShardedRolloutCollector); anything missing is allocated here."""
         self.engine = engine
         self.T = int(episode_length)
         self.use_centralized_V = bool(use_centralized_V)
         c, dev = engine.cfg, engine.device
-        N, A, E, D = c.num_envs, c.num_agents, c.num_entities, c.obs_dim
-        T1 = self.T + 1
-        f32, i32 = torch.float32, torch.int32
-        self.obs = torch.zeros((T1, N, A, D), dtype=f32, device=dev)
-        self.node_obs = torch.zeros((T1, N, A, E, c.node_feats), dtype=f32, device=dev)
-        adj_shape = (T1, N, E, E) if engine.adj_compact else (T1, N, A, E, E)
-        self._adj = torch.zeros(adj_shape, dtype=f32, device=dev)
-        self.agent_id = torch.zeros((T1, N, A, 1), dtype=i32, device=dev)
-        self.rewards = torch.zeros((self.T, N, A, 1), dtype=f32, device=dev)
-        self.dones = torch.zeros((self.T, N, A), dtype=torch.uint8, device=dev)
-        self.masks = torch.ones((T1, N, A, 1), dtype=f32, device=dev)
-        self.active_masks = torch.ones((T1, N, A, 1), dtype=f32, device=dev)
+        self.node_form = getattr(engine, "node_form", "rows")
+        storage = dict(storage or {})
+        for name, (dt, shape) in storage_spec(c, self.T, engine.adj_compact, self.node_form).items():
+            t = storage.pop(name, None)
+            if t is None:
+                t = (torch.ones if name in ("masks", "active_masks") else torch.zeros)(shape, dtype=dt, device=dev)
+            elif tuple(t.shape) != tuple(shape) or t.dtype != dt or t.device != dev or not t.is_contiguous():
+                raise ValueError("storage[%r] must be a contiguous %s tensor of shape %s on %s" % (name, dt, tuple(shape), dev))
+            elif name in ("masks", "active_masks"):
+                t.fill_(1.0)
+            setattr(self, name if name != "node_obs" else "_node_obs", t)
+        if storage:
+            raise ValueError("unknown storage entries: %s" % sorted(storage))
+        if self.node_form == "table":
+            self._node_obs = None
+        if self.node_form == "rows":
+            self.entity_table = None
         self.info = torch.zeros_like(engine.out.info) if engine.out.info is not None else None
         self.step = 0
+
+    @property
+    def node_obs(self):
+        """[T+1, N, A, E, F]. With node_form "table" the rows are expanded from the entity tables on demand (gmpe_expand_node_obs: bit-identical to the rows the engine
+        would have written) — a fresh tensor every call; a learner keeps the result, a rank that only ships its rollout never asks."""
+        if self._node_obs is not None:
+            return self._node_obs
+        return self.engine.expand_node_obs(self.entity_table)
 
     # ------------------------------------------------------------------ views with the reference's shapes
     @property
@@ -62,8 +97,8 @@ class DeviceRolloutBuffer(object):
     # ------------------------------------------------------------------ filling
     def _bind(self, slot, reward_slot):
         e = self.engine
-        o = StepOutputs(obs=self.obs[slot], agent_id=self.agent_id[slot], node_obs=self.node_obs[slot],
-                        adj=self._adj[slot],
+        o = StepOutputs(obs=self.obs[slot], agent_id=self.agent_id[slot], node_obs=None if self._node_obs is None else self._node_obs[slot],
+                        entity_table=None if self.entity_table is None else self.entity_table[slot], adj=self._adj[slot],
                         reward=self.rewards[reward_slot].view(e.N, e.A) if reward_slot is not None else e.out.reward,
                         done=self.dones[reward_slot] if reward_slot is not None else e.out.done, info=self.info)
         e.rebind(o)
@@ -91,7 +126,9 @@ class DeviceRolloutBuffer(object):
         t, e = self.step, self.engine
         dev = e.device
         put = lambda dst, src: dst.copy_(torch.as_tensor(src).to(device=dev, dtype=dst.dtype).reshape(dst.shape))
-        put(self.obs[t + 1], obs); put(self.agent_id[t + 1], agent_id); put(self.node_obs[t + 1], node_obs)
+        if self._node_obs is None:
+            raise ValueError("insert_external takes node_obs rows: the buffer's engine must keep them (node_form 'rows' or 'both')")
+        put(self.obs[t + 1], obs); put(self.agent_id[t + 1], agent_id); put(self._node_obs[t + 1], node_obs)
         a = torch.as_tensor(adj)
         if e.adj_compact and a.dim() == 4:
             a = a[:, 0]                                   # the A per-agent matrices are one matrix (…_july.py:1625)
@@ -113,9 +150,11 @@ class DeviceRolloutBuffer(object):
                 self.insert_step(action_sets[k % action_sets.shape[0]])
             return e.out
         NA = e.N * e.A
-        slot0 = StepOutputs(obs=self.obs[1], agent_id=self.agent_id[1], node_obs=self.node_obs[1], adj=self._adj[1],
+        slot0 = StepOutputs(obs=self.obs[1], agent_id=self.agent_id[1], node_obs=None if self._node_obs is None else self._node_obs[1],
+                            entity_table=None if self.entity_table is None else self.entity_table[1], adj=self._adj[1],
                             reward=self.rewards[0].view(e.N, e.A), done=self.dones[0], info=self.info)
-        strides = dict(obs=self.obs[0].numel(), agent_id=NA, node_obs=self.node_obs[0].numel(), adj=self._adj[0].numel(),
+        strides = dict(obs=self.obs[0].numel(), agent_id=NA, node_obs=0 if self._node_obs is None else self._node_obs[0].numel(),
+                       entity_table=0 if self.entity_table is None else self.entity_table[0].numel(), adj=self._adj[0].numel(),
                        reward=NA, done=NA, info=0, masks=NA)
         e.rollout(action_sets, K, slot0=slot0, num_slots=self.T, first_slot=self.step, strides=strides,
                   masks=self.masks[1], active_masks=self.active_masks[1])
@@ -127,5 +166,15 @@ class DeviceRolloutBuffer(object):
 
     def after_update(self):
         """graph_buffer.py:253-283: the last slot becomes slot 0 of the next rollout."""
-        for buf in (self.obs, self.node_obs, self._adj, self.agent_id, self.masks, self.active_masks):
+        for buf in self._carried():
             buf[0].copy_(buf[-1])
+
+    def _carried(self):
+        return [b for b in (self.obs, self._node_obs, self.entity_table, self._adj, self.agent_id, self.masks, self.active_masks) if b is not None]
+
+    def carry_from(self, other):
+        """after_update across TWO buffers that alternate (sharding.ShardedRolloutCollector): slot 0 of this one = the last slot of `other`, and the engine's
+        outputs are re-bound to this buffer's storage by the next collect / insert_step."""
+        for dst, src in zip(self._carried(), other._carried()):
+            dst[0].copy_(src[-1])
+        self.step = 0

@@ -137,3 +137,146 @@ class RolloutGather(object):
         if g is None:
             return None
         return unpack_gathered(g, self.world, *self.dims)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Gather at ROLLOUT granularity, compact node form (SURVEY §8e "state + one E×E per env")
+# ---------------------------------------------------------------------------------------------------------------------------------------
+_ROLLOUT_SECTIONS = ("obs", "entity_table", "_adj", "rewards", "dones", "masks", "active_masks")     # agent_id is arange(A): regenerated by the learner, not shipped
+
+
+def rollout_slab_layout(cfg, episode_length):
+    """Byte layout of one rank's rollout slab: the env-side arrays of a T-step rollout (rollout.storage_spec, compact adjacency, node features as the fp64 entity
+    table) back to back, every section 16-byte aligned. -> ({name: (offset, nbytes, dtype, shape)}, total bytes)."""
+    from .rollout import storage_spec
+    spec = storage_spec(cfg, episode_length, adj_compact=True, node_form="table")
+    off, out = 0, {}
+    for name in _ROLLOUT_SECTIONS:
+        dt, shape = spec[name]
+        n = 1
+        for s in shape:
+            n *= int(s)
+        nbytes = n * torch.empty((), dtype=dt).element_size()
+        out[name] = (off, nbytes, dt, tuple(int(s) for s in shape))
+        off = (off + nbytes + 15) // 16 * 16
+    return out, off
+
+
+def rollout_slab_views(slab, layout):
+    """Typed views of one rollout slab (contiguous uint8 tensor)."""
+    return {name: slab[o:o + nb].view(dt).view(shape) for name, (o, nb, dt, shape) in layout.items()}
+
+
+def rollout_bytes_per_env_step(cfg, episode_length=25, form="compact"):
+    """Bytes a rank ships per env-step. form: "rows" = the round-3 slab (obs + node_obs rows + one ExE adj + reward + done), "compact" = this
+    module's rollout slab (obs + entity table + one ExE adj + reward + done + masks), "materialised" = what GraphSubprocVecEnv's workers pickle (A adjacency copies)."""
+    A, E, D, F, W = cfg.num_agents, cfg.num_entities, cfg.obs_dim, cfg.node_feats, cfg.entity_table_width
+    if form == "rows":
+        return 4 * A * D + 4 * A * E * F + 4 * E * E + 4 * A + A
+    if form == "materialised":
+        return 4 * A * D + 4 * A * E * F + 4 * A * E * E + 4 * A + A
+    T = float(episode_length)
+    return (4 * A * D + 8 * W + 4 * E * E + 8 * A) * (T + 1) / T + 4 * A + A
+
+
+class ShardedRolloutCollector(object):
+    """The runner's collect loop (graph_mpe_runner.py:57-103) on every rank's env shard + ONE collective per T-step rollout that moves the rank's rollout slab to
+    the learner rank — what replaces GraphSubprocVecEnv.step_wait's per-step `remote.recv()` loop (env_wrappers.py:996-1004) for a GraphReplayBuffer-shaped consumer
+    (graph_buffer.py:168-251).
+
+    * Launch shape: `DeviceRolloutBuffer.collect` = one launch of the persistent rollout kernel per T steps (the headline launch shape), writing straight into the slab.
+    * Slab: obs + the fp64 ENTITY TABLE (the per-entity state node_obs is a pure function of: ~8x fewer bytes than the [A,E,F] rows) + one ExE adjacency per env +
+      rewards / dones / masks; the learner rebuilds the node rows bit for bit with gmpe_expand_node_obs straight into its global [T+1, world*N, A, E, F] array.
+    * Two slabs alternate: the gather of rollout k runs on RCCL's stream while rollout k+1 is collected (slot 0 of the next rollout is carried over first).
+    Every rank must hold the same number of envs. The engine must be created with adj_compact=True, node_form="table"."""
+
+    def __init__(self, engine, episode_length, world, rank=None, group=None, dst=0, expand=None):
+        import torch.distributed as dist
+        from .rollout import DeviceRolloutBuffer
+        if not engine.adj_compact or getattr(engine, "node_form", "rows") != "table":
+            raise ValueError("ShardedRolloutCollector needs an engine created with adj_compact=True, node_form='table' (it ships one ExE matrix and the entity table per env-step)")
+        self.dist, self.group, self.dst = dist, group, int(dst)
+        self.engine, self.world, self.T = engine, int(world), int(episode_length)
+        self.rank = dist.get_rank(group) if rank is None else int(rank)
+        self.cfg = engine.cfg
+        self.layout, self.slab_bytes = rollout_slab_layout(self.cfg, self.T)
+        dev = engine.device
+        n = torch.tensor([self.cfg.num_envs], dtype=torch.int64, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+        lo, hi = n.clone(), n.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group); dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        if int(lo.item()) != int(hi.item()):
+            raise ValueError("ShardedRolloutCollector: every rank must hold the same number of envs (got %d..%d)" % (int(lo.item()), int(hi.item())))
+        self.slabs = [torch.zeros(self.slab_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.bufs = [DeviceRolloutBuffer(engine, self.T, storage=rollout_slab_views(s, self.layout)) for s in self.slabs]
+        self.gathered = [torch.zeros((self.world, self.slab_bytes), dtype=torch.uint8, device=dev) if self.rank == self.dst else None for _ in range(2)]
+        self._work = [None, None]
+        self._flip = 0
+        self._last = None
+        self._expand = expand
+
+    def warmup(self):
+        """GMPERunner.warmup (graph_mpe_runner.py:213-238): the reset observations go to slot 0 of the first rollout."""
+        self.bufs[0].warmup()
+        self._flip, self._last = 0, None
+
+    def _issue(self, b):
+        d, g = self.dist, self.group
+        dst_global = self.dst if g is None else d.get_global_rank(g, self.dst)
+        lst = list(self.gathered[b].unbind(0)) if self.rank == self.dst else None
+        return d.gather(self.slabs[b], lst, dst=dst_global, group=g, async_op=True)
+
+    def collect_and_gather_async(self, action_sets, num_steps=None):
+        """One T-step rollout into the next slab (ONE launch), then start its gather; returns the slab index. The previous gather of that slab is waited for first."""
+        b = self._flip
+        self._flip ^= 1
+        if self._work[b] is not None:
+            self._work[b].wait(); self._work[b] = None
+        if self._last is not None and self._last != b:
+            self.bufs[b].carry_from(self.bufs[self._last])          # after_update across the two slabs: slot 0 <- the previous rollout's last slot
+        elif self._last == b:
+            self.bufs[b].after_update()
+        self.bufs[b].collect(action_sets, num_steps)
+        self._last = b
+        self._work[b] = self._issue(b)
+        return b
+
+    def wait(self, b):
+        if self._work[b] is not None:
+            self._work[b].wait(); self._work[b] = None
+        return self.gathered[b]
+
+    def unpack(self, b, out=None):
+        """Learner rank: global arrays of rollout slab `b` in env order (rank-major) — obs [T+1, W*N, A, D], node_obs [T+1, W*N, A, E, F] (expanded from every rank's
+        entity table straight into place), adj [T+1, W*N, E, E] (the [.., A, E, E] form is its broadcast view), rewards [T, W*N, A, 1], dones bool [T, W*N, A], masks,
+        active_masks, agent_id. `out`: dict of preallocated tensors to fill (a learner's GraphReplayBuffer storage). None on the other ranks."""
+        g = self.wait(b)
+        if g is None:
+            return None
+        c, Wd = self.cfg, self.world
+        N, A, E = c.num_envs, c.num_agents, c.num_entities
+        per = [rollout_slab_views(g[r], self.layout) for r in range(Wd)]
+        out = {} if out is None else out
+        dev = g.device
+
+        def dest(name, dt, shape):
+            if name not in out:
+                out[name] = torch.empty(shape, dtype=dt, device=dev)
+            return out[name]
+        for name, key in (("obs", "obs"), ("adj", "_adj"), ("rewards", "rewards"), ("masks", "masks"), ("active_masks", "active_masks")):
+            _, _, dt, shape = self.layout[key]
+            dst = dest(name, dt, (shape[0], Wd * N) + shape[2:])
+            for r in range(Wd):
+                dst[:, r * N:(r + 1) * N].copy_(per[r][key])
+        dn = dest("dones", torch.bool, (self.T, Wd * N, A))
+        for r in range(Wd):
+            dn[:, r * N:(r + 1) * N].copy_(per[r]["dones"] != 0)
+        T1 = self.T + 1
+        node = dest("node_obs", torch.float32, (T1, Wd * N, A, E, c.node_feats))
+        expand = self._expand
+        if expand is None:
+            from .engine import expand_node_obs as expand
+        for r in range(Wd):
+            expand(c, per[r]["entity_table"].contiguous(), out=node, out_envs=Wd * N, env_offset=r * N)
+        if "agent_id" not in out:
+            out["agent_id"] = torch.arange(A, dtype=torch.int32, device=dev).view(1, 1, A, 1).expand(T1, Wd * N, A, 1)
+        return out

@@ -185,6 +185,12 @@ typedef struct gmpe_outputs {
     float*   info;       /* [N,A,GMPE_INFO_KEYS] (step only; optional) (…_july.py:741-829)             */
     int32_t  adj_compact;/* 1: write the single E×E matrix every ego shares            */
     int32_t  reserved;
+    /* ---- ABI 3 ---- */
+    double*  entity_table;/* [N,W] f64, W = gmpe_entity_table_width(cfg), or NULL: the per-entity state the node_obs rows of this step are a pure function of —
+                            what a rank SHIPS instead of the [N,A,E,F] rows (SURVEY §8e "state + one E×E per env"); gmpe_expand_node_obs rebuilds the rows
+                            bit for bit on the learner. Layout per env: x[E], y[E] of every entity (agents after the move / after a reset), then per agent
+                            vox[A], voy[A] (velocity BEFORE this step's reward loop), vnx[A], vny[A] (AFTER it: re-drawn heading on a goal reach, core.py:324-333);
+                            rot_inv family: + cos[A], sin[A] of the post-reward heading; two_phase_graph: + exit x, exit y (its goal node feature)   */
 } gmpe_outputs;
 
 int gmpe_abi_version(void);
@@ -194,6 +200,7 @@ const char* gmpe_last_error(void);
 int gmpe_obs_dim(const gmpe_config* cfg);
 int gmpe_node_feats(const gmpe_config* cfg);   /* 8; 7 for the rot_inv family and for graph_feat_type = 1 */
 int gmpe_num_entities(const gmpe_config* cfg);
+int gmpe_entity_table_width(const gmpe_config* cfg);   /* W of gmpe_outputs.entity_table: 2E + 4A (+ 2A rot_inv family) (+ 2 two_phase_graph) doubles per env */
 
 /* Create the engine on HIP device `device`. Replaces N x `GraphMPEEnv(args)` + `env.seed(seed +
  * rank*1000)` (multiagent/MPE_env.py:56-84, onpolicy/scripts/train_mpe.py:21-43). */
@@ -260,6 +267,7 @@ typedef struct gmpe_rollout {
     int64_t stride_obs, stride_agent_id, stride_node_obs, stride_adj, stride_reward, stride_done, stride_info, stride_masks;
     float*  masks;              /* slot 0 of the masks, or NULL                                            */
     float*  active_masks;       /* slot 0 of the active_masks, or NULL                                     */
+    int64_t stride_entity_table;/* ABI 3: elements (doubles) between consecutive slots of gmpe_outputs.entity_table */
 } gmpe_rollout;
 int gmpe_rollout_steps(gmpe_handle* h, const int32_t* actions_dev, const gmpe_rollout* plan, const gmpe_outputs* slot0, void* stream);
 
@@ -312,6 +320,16 @@ int gmpe_edges_from_adj_compact(gmpe_handle* h, const float* adj_compact_dev, in
                                 float max_edge_dist, int32_t inclusive, int32_t index64, void* edge_index_dev, float* edge_attr_dev,
                                 int64_t cap, int32_t* n_edges_dev, void* stream);
 
+/* Learner side of the compact rollout gather (replaces what GraphSubprocVecEnv.step_wait receives pickled from its workers, onpolicy/envs/env_wrappers.py:996-1004, for
+ * the node features consumed by GraphReplayBuffer.insert, onpolicy/utils/graph_buffer.py:168-251): rebuild node_obs rows from entity tables
+ * (gmpe_outputs.entity_table) with the engine's own arithmetic — same operations in the same order, -ffp-contract=off — so the result is BIT-IDENTICAL to the
+ * node_obs the engine would have written (_get_entity_feat_relative …_july.py:1694-1771 / rot_inv.py:1690-1766, _get_entity_feat_global …_july.py:1672-1691,
+ * including the ordered-visibility rule for re-drawn velocities). Needs no handle (the learner rank may own no envs): `cfg` supplies scenario, feature type and sizes.
+ *   table_dev     f64 [num_blocks, envs_per_block, W]           (e.g. one rank's [T+1, N, W] rollout section)
+ *   node_obs_dev  f32 [num_blocks, out_envs_per_block, A, E, F]  block t, env n -> out env out_env_offset + n (a rank's env range inside the global batch) */
+int gmpe_expand_node_obs(const gmpe_config* cfg, int device, const double* table_dev, int64_t num_blocks, int64_t envs_per_block,
+                         float* node_obs_dev, int64_t out_envs_per_block, int64_t out_env_offset, void* stream);
+
 /* Rollout-buffer masks from a step's dones (GraphReplayBuffer.insert: onpolicy/utils/graph_buffer.py:223-251 with the runner's
  * rules graph_mpe_runner.py:85-90, 395-405): masks f32 [N,A] = 0 where done; active_masks f32 [N,A] = 0 where done unless all agents of
  * the env are done. Either output may be NULL. */
@@ -320,7 +338,7 @@ int gmpe_masks_from_dones(gmpe_handle* h, const uint8_t* done_dev, float* masks_
 /* What gmpe_create chose for this handle (recorded by bench.py next to every number). Environment variables override the heuristics —
  * GMPE_G / GMPE_BLOCK (step tile shape), GMPE_GROLL (rollout tile shape), GMPE_AP=0 (run-time-size instead of exact-size kernels),
  * GMPE_NT / GMPE_ROLLNT (nontemporal graph stores of step / rollout launches), GMPE_SPEC (wave specialisation), GMPE_SPLIT / GMPE_CHUNKS
- * / GMPE_RAMP / GMPE_AHEAD / GMPE_XSTEP (split big-E path, its chunk count, quarter + half first chunks, run-ahead bound, chained steps), GMPE_ROLL (gmpe_step_many as one rollout launch) — none of them changes results
+ * / GMPE_RAMP / GMPE_AHEAD / GMPE_XSTEP (split big-E path, its chunk count, quarter + half first chunks, run-ahead bound, chained steps), GMPE_ROLL (gmpe_step_many as one rollout launch), GMPE_FUSE — none of them changes results
  * (tests/test_gpu_instantiations.py, tests/test_gpu_rollout_kernel.py). */
 typedef struct gmpe_tuning {
     int32_t G;                  /* envs per workgroup (tile)                                               */

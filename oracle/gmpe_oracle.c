@@ -43,6 +43,8 @@ typedef struct gmpo {
     double *goal_min_time, *delta_spacing;
     int32_t* error_flags;
     double* dist;                 /* [N,E,E] world.cached_dist_mag incl. in-place masking */
+    double* etab;                 /* [N,W] entity table of the last step / reset (include/gmpe.h gmpe_outputs.entity_table) */
+    int W;
     const double* tape;
     const double* ovr_ctrl;   /* safety-filter hook slot (multiagent/core.py:692-736): [N,A,2] filtered controls, or NULL */
     const uint8_t* ovr_use;   /* [N,A] `filtered` flags, NULL = everywhere */
@@ -104,6 +106,10 @@ int gmpo_obs_dim(const gmpe_config* c) { return c->scenario == GMPE_SCENARIO_TUB
 int gmpo_node_feats(const gmpe_config* c) { return (is_rotfam(c) || c->graph_feat_type == 1) ? 7 : 8; }
 static inline int is_tube(const gmpe_config* c) { return c->scenario != GMPE_SCENARIO_NAVIGATION_GRAPH; }
 int gmpo_num_entities(const gmpe_config* c) { return c->num_agents + c->num_landmarks + c->num_obstacles; }
+/* width of the entity table (include/gmpe.h gmpe_outputs.entity_table): x[E], y[E], vox / voy / vnx / vny [A] (+ cos / sin [A] rot_inv family) (+ exit x, y two_phase) */
+int gmpo_entity_table_width(const gmpe_config* c) {
+    return 2 * gmpo_num_entities(c) + 4 * c->num_agents + (is_rotfam(c) ? 2 * c->num_agents : 0) + (c->scenario == GMPE_SCENARIO_TWO_PHASE ? 2 : 0);
+}
 
 /* ------------------------------------------------------------------ create / fields */
 #define ALLOC(p, n, T) do { (p) = (T*)calloc((size_t)(n) > 0 ? (size_t)(n) : 1, sizeof(T)); if (!(p)) return GMPE_ERR_INVALID_ARG; } while (0)
@@ -131,6 +137,8 @@ int gmpo_create(const gmpe_config* cfg, gmpo** out) {
     ALLOC(h->spacing_viol, NA, int32_t); ALLOC(h->steps_in_corr, NA, int32_t); ALLOC(h->conformance, NA, int32_t);
     ALLOC(h->goal_min_time, NA, double); ALLOC(h->delta_spacing, h->N, double); ALLOC(h->error_flags, h->N, int32_t);
     ALLOC(h->dist, (size_t)h->N * h->E * h->E, double);
+    h->W = gmpo_entity_table_width(cfg);
+    ALLOC(h->etab, (size_t)h->N * h->W, double);
     for (size_t i = 0; i < NA; ++i) { h->goal_tracker[i] = -1; h->times_required[i] = -1; h->dists_to_goal[i] = -1; h->dist_left[i] = -1; h->goal_reached[i] = -1; }
     *out = h;
     return GMPE_OK;
@@ -141,7 +149,7 @@ int gmpo_destroy(gmpo* h) {
                   h->cooldown, h->goal_tracker, h->current_step, h->rng_ctr, h->tube, h->landmarks, h->obstacles,
                   h->times_required, h->dists_to_goal, h->dist_left, h->goal_reached, h->n_agent_coll,
                   h->n_obst_coll, h->spacing_viol, h->steps_in_corr, h->conformance, h->goal_min_time,
-                  h->delta_spacing, h->error_flags, h->dist};
+                  h->delta_spacing, h->error_flags, h->dist, h->etab};
     for (size_t i = 0; i < sizeof ps / sizeof ps[0]; ++i) free(ps[i]);
     free(h);
     return GMPE_OK;
@@ -202,6 +210,8 @@ static void filtered_control(const gmpo* h, int n, int i, double* u) {
     if (h->ovr_use && !h->ovr_use[na]) return;
     u[0] = h->ovr_ctrl[2 * na]; u[1] = h->ovr_ctrl[2 * na + 1];
 }
+/* entity table of the last step / reset, [N,W] (what a rank ships instead of node_obs; tests compare the engine's table and feed the gloo rehearsal) */
+int gmpo_get_entity_table(gmpo* h, double* dst) { memcpy(dst, h->etab, (size_t)h->N * h->W * 8); return GMPE_OK; }
 /* world.cached_dist_mag after in-place masking, [N,E,E] */
 int gmpo_get_dist_cache(gmpo* h, double* dst) { memcpy(dst, h->dist, (size_t)h->N * h->E * h->E * 8); return GMPE_OK; }
 
@@ -242,6 +252,23 @@ static void ent_pos(const envv* v, int k, double* px, double* py) {
 static void agent_vel(const envv* v, int k, double* vx, double* vy) {
     if (is_kinematic(v->h)) { *vx = v->s3[k] * cos(v->s2[k]); *vy = v->s3[k] * sin(v->s2[k]); }
     else { *vx = v->s2[k]; *vy = v->s3[k]; }
+}
+
+/* Entity table rows of env v (layout: include/gmpe.h). stage 0: positions + the agents' velocities BEFORE the step's reward loop (the value an ego sees for an
+ * agent with a larger index, environment.py:1036-1053); stage 1: the velocities AFTER it (reset_velocity on a goal reach, core.py:324-333), the post-reward heading's
+ * cos / sin and two_phase's exit. A reset calls both stages back to back (nothing moves between them). */
+static void table_stage(envv* v, int stage) {
+    gmpo* h = v->h; const int A = v->A, E = v->E;
+    double* T = h->etab + (size_t)v->n * h->W;
+    double* vo = T + 2 * E; double* vn = vo + 2 * A;
+    if (stage == 0) {
+        for (int k = 0; k < E; ++k) ent_pos(v, k, &T[k], &T[E + k]);
+        for (int a = 0; a < A; ++a) agent_vel(v, a, &vo[a], &vo[A + a]);
+    } else {
+        for (int a = 0; a < A; ++a) agent_vel(v, a, &vn[a], &vn[A + a]);
+        if (is_rotfam(&h->c)) for (int a = 0; a < A; ++a) { vn[2 * A + a] = cos(v->s2[a]); vn[3 * A + a] = sin(v->s2[a]); }
+        if (h->c.scenario == GMPE_SCENARIO_TWO_PHASE) { T[h->W - 2] = v->tube[T_EXX]; T[h->W - 1] = v->tube[T_EXY]; }
+    }
 }
 
 /* World.calculate_distances, core.py:600-624: upper triangle delta, mirrored negated; norm(axis=2). */
@@ -923,6 +950,7 @@ static void env_reset(envv* v, double* obs, int32_t* ids, double* node, double* 
     h->current_step[v->n] = 0;
     if (is_tube(&h->c)) reset_world_july(v); else reset_world_nav(v);
     calculate_distances(v);                     /* initialize_min_time_distance_graph (735-739) */
+    table_stage(v, 0); table_stage(v, 1);
     double otmp[32], ntmp[GMPE_MAX_ENTITIES * 8];
     const int F = h->F, rotinv = is_rotfam(&h->c);
     for (int i = 0; i < A; ++i) {
@@ -1011,6 +1039,7 @@ static int env_step(envv* v, const int32_t* act, double* obs, int32_t* ids, doub
         for (int i = 0; i < A; ++i) { v->x[i] = pos[2 * i]; v->y[i] = pos[2 * i + 1]; v->s2[i] = vel[2 * i]; v->s3[i] = vel[2 * i + 1]; }
     }
     calculate_distances(v);
+    table_stage(v, 0);
     double otmp[32], ntmp[GMPE_MAX_ENTITIES * 8], itmp[GMPE_INFO_KEYS], rsum = 0;
     int all_done = 1;
     for (int i = 0; i < A; ++i) {                /* environment.py:1036-1053, IN ORDER */
@@ -1029,6 +1058,7 @@ static int env_step(envv* v, const int32_t* act, double* obs, int32_t* ids, doub
     }
     if (c->collaborative && rew) for (int i = 0; i < A; ++i) rew[i] = rsum;   /* environment.py:1056-1061 */
     if (adj) memcpy(adj, v->dist, sizeof(double) * E * E);
+    table_stage(v, 1);
     if (all_done && auto_reset) { env_reset(v, obs, ids, node, adj); return 1; }
     return 0;
 }

@@ -34,6 +34,8 @@ def load():
     lib.gmpo_set_rng_tape.argtypes = [P, P, C.c_int64]
     lib.gmpo_set_control_override.argtypes = [P, P, P]
     lib.gmpo_get_dist_cache.argtypes = [P, P]
+    lib.gmpo_get_entity_table.argtypes = [P, P]
+    lib.gmpo_entity_table_width.argtypes = [C.POINTER(GmpeConfig)]
     lib.gmpo_reset.argtypes = [P, P, P, P, P, P]
     lib.gmpo_step.argtypes = [P, P, P, P, P, P, P, P, P, P, C.c_int]
     lib.gmpo_update_graph.argtypes = [P, C.c_int, P, P, C.c_int]
@@ -121,6 +123,12 @@ class Oracle(object):
         self.lib.gmpo_step(self.h, _p(a), _p(obs), _p(ids), _p(node), _p(adj), _p(rew), _p(done), _p(info),
                            _p(did), int(auto_reset))
         return obs, ids, node, adj, rew, done.astype(bool), info, did.astype(bool)
+
+    def entity_table(self):
+        """[N, W] table of the last step / reset (what a rank ships instead of node_obs; include/gmpe.h gmpe_outputs.entity_table)."""
+        t = np.zeros((self.N, self.cfg.entity_table_width))
+        self.lib.gmpo_get_entity_table(self.h, _p(t))
+        return t
 
     def dist_cache(self):
         d = np.zeros((self.N, self.E, self.E))

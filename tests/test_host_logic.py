@@ -203,29 +203,60 @@ class _OracleBackedEngine(object):
     output tensors from the CPU oracle — so the gather path (slab views, rebind, collective, unpack) runs on CPU with the real
     shapes and values of a real config. Test infrastructure only; the GPU twin is tests/test_gpu_vec_env.py::test_rollout_gather_real_engine."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, node_form="rows", do_reset=True):
         import torch
         import oracle_lib as ol
         from gmpe.engine import StepOutputs
-        self.cfg, self.adj_compact, self.device = cfg, True, torch.device("cpu")
+        self.cfg, self.adj_compact, self.device, self.node_form = cfg, True, torch.device("cpu"), node_form
         N, A, E, D, F = cfg.num_envs, cfg.num_agents, cfg.num_entities, cfg.obs_dim, cfg.node_feats
+        self.N, self.A = N, A
         self.orc = ol.Oracle(cfg)
-        self.orc.reset()
-        self.out = StepOutputs(obs=torch.zeros(N, A, D), agent_id=torch.zeros(N, A, 1, dtype=torch.int32), node_obs=torch.zeros(N, A, E, F),
+        if do_reset:
+            self.orc.reset()
+        self.out = StepOutputs(obs=torch.zeros(N, A, D), agent_id=torch.zeros(N, A, 1, dtype=torch.int32),
+                               node_obs=torch.zeros(N, A, E, F) if node_form != "table" else None,
+                               entity_table=torch.zeros(N, cfg.entity_table_width, dtype=torch.float64) if node_form != "rows" else None,
                                adj=torch.zeros(N, E, E), reward=torch.zeros(N, A), done=torch.zeros(N, A, dtype=torch.uint8), info=None)
 
     def rebind(self, o):
-        for k in ("obs", "node_obs", "adj", "reward", "done"):
-            assert getattr(o, k).shape == getattr(self.out, k).shape and getattr(o, k).dtype == getattr(self.out, k).dtype and getattr(o, k).is_contiguous(), k
+        for k in ("obs", "node_obs", "entity_table", "adj", "reward", "done"):
+            a, b = getattr(o, k), getattr(self.out, k)
+            assert (a is None) == (b is None), k
+            assert a is None or (a.shape == b.shape and a.dtype == b.dtype and a.is_contiguous()), k
         self.out = o
+
+    def tuning(self):
+        return {"split": 1, "roll": 0}                       # DeviceRolloutBuffer.collect then takes its insert_step loop (no rollout kernel on the CPU)
+
+    def _fill(self, obs, node, adj):
+        import torch
+        o = self.out
+        o.obs.copy_(torch.from_numpy(obs)); o.adj.copy_(torch.from_numpy(adj))
+        if o.node_obs is not None:
+            o.node_obs.copy_(torch.from_numpy(node))
+        if o.entity_table is not None:
+            o.entity_table.copy_(torch.from_numpy(self.orc.entity_table()))
+        if o.agent_id is not None:
+            o.agent_id.copy_(torch.arange(self.A, dtype=torch.int32).view(1, self.A, 1).expand(self.N, self.A, 1))
+
+    def reset(self):
+        obs, ids, node, adj = self.orc.reset()
+        self._fill(obs, node, adj)
+        return self.out
 
     def step(self, act):
         import torch
-        obs, ids, node, adj, rew, done, info, did = self.orc.step(act)
+        obs, ids, node, adj, rew, done, info, did = self.orc.step(act.numpy() if torch.is_tensor(act) else act)
+        self._fill(obs, node, adj)
         o = self.out
-        o.obs.copy_(torch.from_numpy(obs)); o.node_obs.copy_(torch.from_numpy(node)); o.adj.copy_(torch.from_numpy(adj))
         o.reward.copy_(torch.from_numpy(rew)); o.done.copy_(torch.from_numpy(done.astype(np.uint8)))
         return o
+
+    def masks_from_dones(self, done, masks, active_masks):
+        """GraphReplayBuffer.insert's mask rules (graph_buffer.py:223-251, graph_mpe_runner.py:395-405) — what gmpe_masks_from_dones computes on the device"""
+        d = done.bool()
+        alld = d.all(dim=1, keepdim=True)
+        masks.copy_((~d).float().view(masks.shape)); active_masks.copy_((~(d & ~alld)).float().view(active_masks.shape))
 
 
 def _gather_worker(rank, world, port, q, scen, mode):
@@ -285,6 +316,124 @@ def test_rollout_gather_rejects_unequal_shards_and_wrong_layout():
     assert v["node_obs"].shape == (5, 3, 6, 7) and v["done"].dtype == torch.uint8 and v["adj"].shape == (5, 6, 6)
     with pytest.raises(TypeError):
         slab_layout(5, 3, 6, 13)                              # F has no default any more (round-1 bug: F = 8 assumed)
+
+
+# ---------------------------------------------------------------- rollout-granularity gather of the compact slab (world_size 2, gloo)
+def _numpy_expand(cfg, table, out=None, out_envs=None, env_offset=0):
+    """CPU stand-in for gmpe_expand_node_obs (TEST infrastructure for the gloo rehearsal only; the HIP kernel is checked bit for bit against the engine's own rows in
+    tests/test_gpu_gather.py): node rows from entity tables, the three row variants of gmpe_kernel.h stream_graph_fn."""
+    import torch
+    t = table.numpy()
+    A, L, E, F, W = cfg.num_agents, cfg.num_landmarks, cfg.num_entities, cfg.node_feats, cfg.entity_table_width
+    lead, n = t.shape[:-2], t.shape[-2]
+    T = t.reshape(-1, W)
+    ex, ey = T[:, :E], T[:, E:2 * E]
+    vox, voy, vnx, vny = (T[:, 2 * E + q * A:2 * E + (q + 1) * A] for q in range(4))
+    B = T.shape[0]
+    ego = np.arange(A)[None, :, None]; k = np.arange(E)[None, None, :]
+    kag = k < A; kk = np.where(kag, k, 0)
+    post = k <= ego
+    take = lambda a: np.take_along_axis(a[:, None, :].repeat(A, 1), np.broadcast_to(kk, (B, A, E)), axis=2)
+    kvx = np.where(kag, np.where(post, take(vnx), take(vox)), 0.0); kvy = np.where(kag, np.where(post, take(vny), take(voy)), 0.0)
+    kx = np.broadcast_to(ex[:, None, :], (B, A, E)); ky = np.broadcast_to(ey[:, None, :], (B, A, E))
+    gxa = np.take_along_axis(ex[:, None, :].repeat(A, 1), np.broadcast_to(A + kk, (B, A, E)), axis=2)
+    gya = np.take_along_axis(ey[:, None, :].repeat(A, 1), np.broadcast_to(A + kk, (B, A, E)), axis=2)
+    px, py = ex[:, :A, None], ey[:, :A, None]; evx, evy = vnx[:, :, None], vny[:, :, None]
+    typ = np.where(kag, 0.0, np.where(k < A + L, 1.0, 2.0)) * np.ones((B, A, E))
+    rot = cfg.scenario in gcfg.ROT_FAMILY
+    f32 = np.float32
+    if cfg.graph_feat_type == 1:
+        rows = np.stack([kvx.astype(f32), kvy.astype(f32), kx.astype(f32), ky.astype(f32), np.where(kag, gxa, kx).astype(f32), np.where(kag, gya, ky).astype(f32), typ.astype(f32)], -1)
+    elif rot:
+        cs, sn = T[:, 2 * E + 4 * A:2 * E + 5 * A, None], T[:, 2 * E + 5 * A:2 * E + 6 * A, None]
+        two = cfg.scenario == gcfg.SCENARIO_TWO_PHASE
+        gx = (T[:, W - 2, None, None].astype(f32) if two else gxa.astype(f32)) * np.ones((B, A, E), f32)
+        gy = (T[:, W - 1, None, None].astype(f32) if two else gya.astype(f32)) * np.ones((B, A, E), f32)
+        rvx = (kvx.astype(f32) - evx.astype(f32)).astype(np.float64); rvy = (kvy.astype(f32) - evy.astype(f32)).astype(np.float64)
+        rpx = (kx.astype(f32) - px.astype(f32)).astype(np.float64); rpy = (ky.astype(f32) - py.astype(f32)).astype(np.float64)
+        rgx = (gx - px.astype(f32)).astype(np.float64); rgy = (gy - py.astype(f32)).astype(np.float64)
+        r2 = lambda vx, vy: (cs * vx + sn * vy, -sn * vx + cs * vy)
+        o0, o1 = r2(rvx, rvy); o2, o3 = r2(rpx, rpy); o4, o5 = r2(rgx, rgy)
+        o4 = np.where(kag, o4, o2); o5 = np.where(kag, o5, o3)
+        rows = np.stack([o0, o1, o2, o3, o4, o5, typ], -1).astype(f32)
+    else:
+        rows = np.stack([kvx - evx, kvy - evy, kx - px, ky - py, np.where(kag, gxa, kx) - px, np.where(kag, gya, ky) - py, np.where(kag, 0.0, 1.0) * np.ones((B, A, E)), typ], -1).astype(f32)
+    rows = torch.from_numpy(rows.reshape(lead + (n, A, E, F)))
+    if out is None:
+        return rows
+    out[..., env_offset:env_offset + n, :, :, :] = rows
+    return out
+
+
+def _collector_worker(rank, world, port, q, scen):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as ol
+    from gmpe.sharding import ShardedRolloutCollector, shard_range
+    NT, A, T = 10, 4, 6
+    kw = dict(scenario_name=scen, num_agents=A, world_size=4.0, episode_length=4, seed=8)
+    lo, hi = shard_range(NT, world, rank)
+    eng = _OracleBackedEngine(gmpe.make_config(num_envs=hi - lo, env_id_base=lo, **kw), node_form="table", do_reset=False)
+    full = ol.Oracle(gmpe.make_config(num_envs=NT, **kw))
+    col = ShardedRolloutCollector(eng, T, world, expand=_numpy_expand)
+    col.warmup()
+    r0 = full.reset()
+    rng = np.random.RandomState(2)
+    ok = True
+    F = eng.cfg.node_feats
+    prev_last = None
+    for rep in range(3):                                      # slabs alternate, slot 0 carried across; auto-resets inside every rollout
+        acts = rng.randint(0, eng.cfg.n_actions, (T, NT, A)).astype(np.int32)
+        ref = [full.step(acts[t]) for t in range(T)]
+        b = col.collect_and_gather_async(torch.from_numpy(acts[:, lo:hi].copy()))
+        u = col.unpack(b)
+        if rank != 0:
+            ok = ok and u is None
+            continue
+        first = (r0[0], r0[2], r0[3]) if rep == 0 else prev_last
+        obs = np.stack([first[0]] + [r[0] for r in ref]).astype(np.float32)
+        node = np.stack([first[1]] + [r[2] for r in ref])
+        adj = np.stack([first[2]] + [r[3] for r in ref]).astype(np.float32)
+        ok = ok and u["node_obs"].shape == (T + 1, NT, A, eng.cfg.num_entities, F)
+        ok = ok and np.array_equal(u["obs"].numpy(), obs) and np.array_equal(u["adj"].numpy(), adj)
+        ok = ok and np.allclose(u["node_obs"].numpy(), node, rtol=0, atol=1e-6)
+        ok = ok and np.array_equal(u["rewards"].numpy()[..., 0], np.stack([r[4] for r in ref]).astype(np.float32))
+        dn = np.stack([r[5] for r in ref])
+        ok = ok and np.array_equal(u["dones"].numpy(), dn)
+        alld = dn.all(axis=2, keepdims=True)
+        ok = ok and np.array_equal(u["masks"].numpy()[1:, ..., 0], (~dn).astype(np.float32))
+        ok = ok and np.array_equal(u["active_masks"].numpy()[1:, ..., 0], (~(dn & ~alld)).astype(np.float32))
+        prev_last = (ref[-1][0], ref[-1][2], ref[-1][3])
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scen", ["nav_metered_one_goal_graph_rotate_tube_july", "two_phase_graph", "navigation_graph"])
+def test_sharded_rollout_collector_world_size_2_gloo(scen):
+    """Per-rollout gather of the compact slab (obs + entity table + one ExE adj + rewards / dones / masks), two ranks: the learner's unpacked arrays == the unsharded run's
+    [T+1, N, ...] rollout, node rows rebuilt from the tables, over three alternating slabs. Replaces env_wrappers.py:996-1004 at rollout granularity."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29100 + (os.getpid() % 2000) + (hash(scen) % 50)
+    ps = [ctx.Process(target=_collector_worker, args=(r, 2, port, q, scen)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    [p.join(60) for p in ps]
+    assert res == [(0, True), (1, True)]
+
+
+def test_rollout_slab_is_compact():
+    """bytes a rank ships per env-step, rows form (round 3) vs compact rollout slab."""
+    from gmpe.sharding import rollout_bytes_per_env_step, rollout_slab_layout
+    c3 = gmpe.make_config(num_envs=4096, num_agents=10)
+    rows, compact = rollout_bytes_per_env_step(c3, 25, "rows"), rollout_bytes_per_env_step(c3, 25, "compact")
+    assert rows == 8810 and compact < 3300 and rows / compact > 2.6
+    lay, total = rollout_slab_layout(c3, 25)
+    assert total % 16 == 0 and all(o % 16 == 0 for o, _, _, _ in lay.values()) and "node_obs" not in lay and lay["entity_table"][3] == (26, 4096, 80)
+    assert abs(total / (25 * 4096) - compact) < 8
 
 
 # ---------------------------------------------------------------- oracle self-consistency (CPU)
