@@ -481,8 +481,41 @@ def main():
         tg = torch.tensor([time.perf_counter() - tg0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         gather = {"value": world * n_envs * kg / float(tg.item()), "unit": "env-steps/s", "steps": kg, "slab_bytes_per_rank": rg.slab_bytes,
-                  "what": "closed-loop step (one launch) + RCCL gather of the compact rollout slab (obs, node_obs, ExE adj, reward, done) "
+                  "what": "PER-STEP shape (round 3): closed-loop step (one launch) + RCCL gather of the rows-form slab (obs, node_obs rows, ExE adj, reward, done) "
                           "to rank 0, gather of step k overlapped with step k+1"}
+        del rg, eng_c
+        # ---- rollout granularity (round 4): ONE launch of the rollout kernel per T steps into the rank's compact slab (obs + fp64 entity table + one ExE adjacency +
+        # rewards / dones / masks) and ONE gather of that slab per rollout, double-buffered; rank 0 rebuilds the node rows (gmpe_expand_node_obs) in its global arrays
+        from gmpe.sharding import ShardedRolloutCollector, rollout_bytes_per_env_step
+        if not (tuning["split"] or not tuning["roll"]):
+            T = cfg.episode_length
+            eng_t = GmpeEngine(mk(), device=local_rank, adj_compact=True, with_info=not args.no_info, node_form="table")
+            col = ShardedRolloutCollector(eng_t, T, world, dst=0)
+            col.warmup()
+            acts_T = actions[:T] if n_act_sets >= T else actions.repeat((T + n_act_sets - 1) // n_act_sets, 1, 1)[:T].contiguous()
+            outbuf = {}
+            for _ in range(2):
+                b = col.collect_and_gather_async(acts_T)
+                col.unpack(b, out=outbuf)
+            n_roll = max(2, min(8, K // T + 1))
+            barrier(); torch.cuda.synchronize(dev)
+            tr0 = time.perf_counter()
+            prev = None
+            for r in range(n_roll):                                  # the gather of rollout r runs while rollout r+1 is collected; rank 0 unpacks r-1 meanwhile
+                b = col.collect_and_gather_async(acts_T)
+                if prev is not None:
+                    col.unpack(prev, out=outbuf)
+                prev = b
+            col.unpack(prev, out=outbuf)
+            torch.cuda.synchronize(dev); barrier()
+            tr = torch.tensor([time.perf_counter() - tr0], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+            gather["rollout"] = {"value": world * n_envs * T * n_roll / float(tr.item()), "unit": "env-steps/s", "rollouts": n_roll, "steps_per_rollout": T,
+                                 "slab_bytes_per_rank": col.slab_bytes, "bytes_per_env_step": rollout_bytes_per_env_step(cfg, T, "compact"),
+                                 "bytes_per_env_step_rows_form": rollout_bytes_per_env_step(cfg, T, "rows"),
+                                 "what": "ONE rollout-kernel launch per T steps into the rank's compact slab + ONE gather of the slab per rollout to rank 0 (two slabs alternate: "
+                                         "the gather of rollout r overlaps the collection of rollout r+1), rank 0 expanding the node rows of every rank's entity tables into its global arrays"}
+            del col, eng_t
 
     if rank == 0:
         B = algorithmic_bytes_per_env_step(cfg, adj_compact=args.adj_compact)      # SURVEY.md §8(d), for the outputs this run really writes
@@ -499,13 +532,20 @@ def main():
                     traffic_src = "profiles/%s_pmc_%s.json: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE in separate runs of this command (NOT measured in this run), scaled to this launch's env-steps" % (tag, args.workload)
                 except Exception:
                     traffic = None
-        fill = None                                    # what a pure streaming-store kernel reaches on this part (tools/fillbw.hip)
-        fj = os.path.join(ROOT, "profiles", "r01_fillbw.json")
-        if os.path.exists(fj):
-            try:
-                fill = json.load(open(fj))["fill_GBps"]["98MB" if B * n_envs < (512 << 20) else "6GB"]
-            except Exception:
-                fill = None
+        # what this launch's store geometry reaches with no compute at all (tools/tilebw.hip via tools/fillbw_r04.sh: persistent tiles, per-tile contiguous blocks,
+        # slot-per-step storage, best of plain / nontemporal stores) at the size class this launch writes per pass over its output storage; newest record first
+        fill, fill_src = None, None
+        pass_bytes = step_bytes * (n_slots if mode == "rollout" else 1)
+        size_key = "98MB" if pass_bytes <= (256 << 20) else ("2.5GB" if pass_bytes <= (4 << 30) else ("6GB" if pass_bytes <= (16 << 30) else "158GB"))
+        for tag in ("r04", "r01"):
+            fj = os.path.join(ROOT, "profiles", "%s_fillbw.json" % tag)
+            if fill is None and os.path.exists(fj):
+                try:
+                    tab = json.load(open(fj))["fill_GBps"]
+                    key = size_key if size_key in tab else ("6GB" if size_key in ("2.5GB", "158GB") and "6GB" in tab else "98MB")
+                    fill, fill_src = tab[key], "profiles/%s_fillbw.json[%s]" % (tag, key)
+                except Exception:
+                    fill = None
         sc = {"navigation_graph": 1 if cfg.num_walls > 0 else 0, "nav_metered_one_goal_graph_rotate_tube_july": 2,
               "nav_graph_metered_single_corridor_rot_inv": 3, "two_phase_graph": 4, "three_phase_graph": 5}[wl["scenario_name"]]
         ap_roll = tuning["ap"] if (tuning["block_roll"] == 256 and tuning["ap"] == 10) else 0       # gmpe_sc.hip launch_env: what fl == 2 dispatches
@@ -541,7 +581,7 @@ def main():
                                       if dram_certain else "the launch overwrites %.0f MB that fit the 256 MiB Infinity Cache: `frac` is algorithmic bytes over the HBM peak, NOT a measured HBM fraction" % (step_bytes / 1e6),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "measured_fill_peak": fill, "frac_of_measured_fill": (achieved / fill) if fill else None,
+                         "measured_fill_peak": fill, "measured_fill_source": fill_src, "frac_of_measured_fill": (achieved / fill) if fill else None,
                          "kernel": kernel, "avg_launch_ms": avg_ms, "launches": launches_per_rep,
                          "timing": "one HIP event pair on the launch stream around the launch(es) of the median repetition",
                          "isolated_launch_ms": iso,

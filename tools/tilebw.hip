@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef float v4f __attribute__((ext_vector_type(4)));
 template <bool NT>
 __global__ __launch_bounds__(256) void tile_store(v4f* __restrict__ adj, v4f* __restrict__ node, v4f* __restrict__ obs, int K, int T, size_t adj_slot4, size_t node_slot4,
@@ -30,7 +31,38 @@ __global__ __launch_bounds__(256) void tile_store(v4f* __restrict__ adj, v4f* __
     }
 }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
-int main() {
+// With arguments — tilebw.bin <label> <tiles> <adj float4 per tile> <node float4 per tile> <obs float4 per tile> <T slots> <K steps> — it measures ONE geometry (streamers 3 / 4,
+// plain / nontemporal, no gap) and prints a JSON line with the best rate: the store ceiling bench.py prices `frac_of_measured_fill` against (tools/fillbw_r04.sh -> profiles/r04_fillbw.json).
+static int one_geometry(const char* label, int tiles, int adj4, int node4, int obs4, int T, int K) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double step_bytes = (double)tiles * (adj4 + node4 + obs4) * 16;
+    v4f *adj, *node, *obs;
+    CK(hipMalloc(&adj, (size_t)T * tiles * adj4 * 16)); CK(hipMalloc(&node, (size_t)T * tiles * node4 * 16)); CK(hipMalloc(&obs, (size_t)T * tiles * obs4 * 16));
+    double best = 0; int best_s = 0, best_nt = 0;
+    for (int streamers : {3, 4}) for (int nt = 0; nt < 2; ++nt) {
+        auto launch = [&] {
+            if (nt) tile_store<true><<<tiles, 256>>>(adj, node, obs, K, T, (size_t)tiles * adj4, (size_t)tiles * node4, (size_t)tiles * obs4, adj4, node4, obs4, streamers, 0);
+            else tile_store<false><<<tiles, 256>>>(adj, node, obs, K, T, (size_t)tiles * adj4, (size_t)tiles * node4, (size_t)tiles * obs4, adj4, node4, obs4, streamers, 0);
+        };
+        launch(); CK(hipDeviceSynchronize());
+        double ms_best = 1e30;
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < ms_best) ms_best = ms;
+        }
+        const double tbps = step_bytes / (ms_best / K * 1e-3) / 1e12;
+        fprintf(stderr, "%s T=%d streamers %d %s: %.2f us per step %.2f TB/s\n", label, T, streamers, nt ? "nt" : "plain", ms_best / K * 1e3, tbps);
+        if (tbps > best) { best = tbps; best_s = streamers; best_nt = nt; }
+    }
+    printf("{\"geometry\": \"%s\", \"tiles\": %d, \"slots\": %d, \"step_MB\": %.1f, \"pass_GB\": %.3f, \"best_GBps\": %.0f, \"best_streaming_waves\": %d, \"best_nontemporal\": %d}\n",
+           label, tiles, T, step_bytes / 1e6, step_bytes * T / 1e9, best * 1e3, best_s, best_nt);
+    CK(hipFree(adj)); CK(hipFree(node)); CK(hipFree(obs));
+    return 0;
+}
+int main(int argc, char** argv) {
+    if (argc == 8) return one_geometry(argv[1], atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]));
+
     const int tiles = 1024, adj4 = 4 * 10 * 400 / 4, node4 = 4 * 10 * 20 * 8 / 4, obs4 = 4 * 10 * 13 / 4 + 2;   // c2: 4 envs per tile
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double step_bytes = (double)tiles * (adj4 + node4 + obs4) * 16;
