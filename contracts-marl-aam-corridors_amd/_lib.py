@@ -16,7 +16,7 @@ SYMBOLS = ["gmpe_abi_version", "gmpe_last_error", "gmpe_obs_dim", "gmpe_node_fea
            "gmpe_timing_enable", "gmpe_timing_read", "gmpe_timing_mark", "gmpe_timing_region_ms",
            "gmpe_rollout_steps", "gmpe_get_tuning", "gmpe_step_many_launches", "gmpe_edges_from_adj_compact",
            "gmpe_set_control_override", "gmpe_field_device_ptr", "gmpe_step_envs", "gmpe_step_many_envs",
-           "gmpe_entity_table_width", "gmpe_expand_node_obs"]
+           "gmpe_entity_table_width", "gmpe_expand_node_obs", "gmpe_expand_adj"]
 
 
 class GmpeOutputs(C.Structure):
@@ -87,6 +87,7 @@ def load():
     lib.gmpe_get_tuning.argtypes = [P, C.POINTER(GmpeTuning)]
     lib.gmpe_entity_table_width.argtypes = [C.POINTER(GmpeConfig)]
     lib.gmpe_expand_node_obs.argtypes = [C.POINTER(GmpeConfig), I, P, C.c_int64, C.c_int64, P, C.c_int64, C.c_int64, P]
+    lib.gmpe_expand_adj.argtypes = [C.POINTER(GmpeConfig), I, P, C.c_int64, C.c_int64, P, C.c_int64, C.c_int64, C.c_int32, P]
     from .config import ABI_VERSION
     if lib.gmpe_abi_version() != ABI_VERSION:
         raise GmpeError("libgmpe.so ABI version mismatch")

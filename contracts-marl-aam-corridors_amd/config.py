@@ -116,9 +116,10 @@ class GmpeConfig(C.Structure):
 
     @property
     def entity_table_width(self):
-        """gmpe_entity_table_width: doubles per env of the entity table (x[E], y[E], vox / voy / vnx / vny [A], + cos / sin [A] rot_inv family, + exit two_phase)."""
+        """gmpe_entity_table_width: doubles per env of the entity table (x[E], y[E], vox / voy / vnx / vny [A], + cos / sin [A] rot_inv family, + exit two_phase,
+        + ceil(E / 32) adjacency-mask words)."""
         return (2 * self.num_entities + 4 * self.num_agents + (2 * self.num_agents if self.scenario in ROT_FAMILY else 0)
-                + (2 if self.scenario == SCENARIO_TWO_PHASE else 0))
+                + (2 if self.scenario == SCENARIO_TWO_PHASE else 0) + (self.num_entities + 31) // 32)
 
     @property
     def node_feats(self):

@@ -681,8 +681,16 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
             const int gg = fdiv(q, W, p.m_TW), w = q - gg * W;
             if (!l.flags[gg * 4 + 3]) continue;
             double val;
+            const int wm = W - (E + 31) / 32;                                // first of the adjacency-mask words (32 node bits per double: exact)
             if (w < 2 * E) val = w < E ? l.ex[gg * E + w] : l.ey[gg * E + (w - E)];
-            else if (SC == SC_TWO && w >= W - 2) val = l.tube[gg * GMPE_TUBE_STRIDE + (w == W - 2 ? T_EXX : T_EXY)];
+            else if (w >= wm) {
+                // this step's adjacency mask (…_july.py:1627-1648: done agents, reached landmarks), so that the learner can rebuild the E x E matrix from the positions
+                unsigned bits = 0;
+                const int k0 = (w - wm) * 32;
+                for (int b = 0; b < 32 && k0 + b < E; ++b) bits |= (l.moff[gg * E + k0 + b] ? 1u : 0u) << b;
+                val = (double)bits;
+            }
+            else if (SC == SC_TWO && w >= wm - 2) val = l.tube[gg * GMPE_TUBE_STRIDE + (w == wm - 2 ? T_EXX : T_EXY)];
             else {
                 const int r = w - 2 * E, blk = fdiv(r, A, p.m_A), a = gg * A + (r - blk * A);
                 val = blk == 0 ? l.vox[a] : blk == 1 ? l.voy[a] : blk == 2 ? l.vnx[a] : blk == 3 ? l.vny[a] : blk == 4 ? l.cn[a] : l.sn[a];

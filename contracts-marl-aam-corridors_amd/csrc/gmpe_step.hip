@@ -346,7 +346,8 @@ __global__ __launch_bounds__(256) void k_node_expand(const double* __restrict__ 
         const double* cn = vny + A; const double* sn = cn + A;
         const float kx = (float)ex[k], ky = (float)ey[k];
         const float kvox = kag ? (float)vox[kk] : 0.0f, kvoy = kag ? (float)voy[kk] : 0.0f, kvnx = kag ? (float)vnx[kk] : 0.0f, kvny = kag ? (float)vny[kk] : 0.0f;
-        const float gxk = two ? (float)T[W - 2] : (kag ? (float)ex[A + kk] : 0.0f), gyk = two ? (float)T[W - 1] : (kag ? (float)ey[A + kk] : 0.0f);
+        const int wx = W - (E + 31) / 32 - 2;                              // two_phase_graph: exit x, y sit right before the mask words
+        const float gxk = two ? (float)T[wx] : (kag ? (float)ex[A + kk] : 0.0f), gyk = two ? (float)T[wx + 1] : (kag ? (float)ey[A + kk] : 0.0f);
         const float apx = (float)ex[ei], apy = (float)ey[ei], avx = (float)vnx[ei], avy = (float)vny[ei];
         const double cs = cn[ei], s_ = sn[ei];
         const float rvx = (post ? kvnx : kvox) - avx, rvy = (post ? kvny : kvoy) - avy;
@@ -366,7 +367,60 @@ __global__ __launch_bounds__(256) void k_node_expand(const double* __restrict__ 
     }
 }
 
+// The E x E adjacency of an env-step from its entity table: f32(sqrt(dx^2 + dy^2)) with delta = pos[min(r,c)] - pos[max(r,c)] (World.calculate_distances,
+// core.py:600-624 — distance_trip's expression, so the bits are the engine's), zero diagonal, rows / columns of masked nodes zeroed (…_july.py:1627-1648).
+// One thread per group of VEC consecutive entries of one matrix; `copies` = 1 writes [.., E, E], `copies` = A the materialised [.., A, E, E].
+template <int VEC>
+__global__ __launch_bounds__(256) void k_adj_from_table(const double* __restrict__ tab, float* __restrict__ out, long long total, int E, int W, int copies,
+                                                        long long n_in, long long n_out, long long off) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int EE = E * E, per = EE / VEC;
+    const long long b = t / per;
+    const int q = (int)(t - b * per) * VEC;
+    const long long blk = b / n_in, n = b - blk * n_in;
+    const double* T = tab + (size_t)b * W;
+    const double* ex = T; const double* ey = T + E;
+    const double* mw = T + (W - (E + 31) / 32);
+    float v[VEC];
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+        const int r = (q + u) / E, c = (q + u) - r * E;
+        const int lo = r < c ? r : c, hi = r < c ? c : r;
+        const unsigned wr = (unsigned)mw[r >> 5], wc = (unsigned)mw[c >> 5];
+        const bool masked = ((wr >> (r & 31)) | (wc >> (c & 31))) & 1u;
+        const double dx = ex[lo] - ex[hi], dy = ey[lo] - ey[hi];
+        v[u] = (r == c || masked) ? 0.0f : (float)sqrt(dx * dx + dy * dy);
+    }
+    float* dst = out + (size_t)(blk * n_out + off + n) * copies * EE + q;
+    for (int a = 0; a < copies; ++a) {
+        if (VEC == 4) *reinterpret_cast<float4*>(dst + (size_t)a * EE) = make_float4(v[0], v[1], v[2], v[3]);
+        else dst[(size_t)a * EE] = v[0];
+    }
+}
+
 extern "C" {
+
+int gmpe_expand_adj(const gmpe_config* cfg, int device, const double* table_dev, int64_t num_blocks, int64_t envs_per_block,
+                    float* adj_dev, int64_t out_envs_per_block, int64_t out_env_offset, int32_t copies, void* stream) {
+    if (!cfg || !table_dev || !adj_dev) return fail(GMPE_ERR_INVALID_ARG, "gmpe_expand_adj: null argument");
+    if (cfg->abi_version != GMPE_ABI_VERSION) return fail(GMPE_ERR_INVALID_ARG, "gmpe_config.abi_version mismatch");
+    if (num_blocks < 0 || envs_per_block < 1 || out_env_offset < 0 || out_env_offset + envs_per_block > out_envs_per_block || copies < 1)
+        return fail(GMPE_ERR_INVALID_ARG, "gmpe_expand_adj: the block's envs do not fit the output's env range");
+    if (num_blocks == 0) return GMPE_OK;
+    const int E = gmpe_num_entities(cfg), W = gmpe_entity_table_width(cfg);
+    if (cfg->num_agents < 1 || cfg->num_agents > GMPE_MAX_AGENTS || E > GMPE_MAX_ENTITIES) return fail(GMPE_ERR_INVALID_ARG, "gmpe_expand_adj: config out of range");
+    HIPCHK(hipSetDevice(device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int EE = E * E, vec = (EE & 3) == 0 ? 4 : 1;
+    const long long total = (long long)num_blocks * envs_per_block * (EE / vec);
+    if ((total + 255) / 256 > 0x7fffffffLL) return fail(GMPE_ERR_INVALID_ARG, "gmpe_expand_adj: too many entries for one launch (split the blocks)");
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (vec == 4) hipLaunchKernelGGL((k_adj_from_table<4>), grid, dim3(256), 0, st, table_dev, adj_dev, total, E, W, (int)copies, (long long)envs_per_block, (long long)out_envs_per_block, (long long)out_env_offset);
+    else hipLaunchKernelGGL((k_adj_from_table<1>), grid, dim3(256), 0, st, table_dev, adj_dev, total, E, W, (int)copies, (long long)envs_per_block, (long long)out_envs_per_block, (long long)out_env_offset);
+    HIPCHK(hipGetLastError());
+    return GMPE_OK;
+}
 
 int gmpe_expand_node_obs(const gmpe_config* cfg, int device, const double* table_dev, int64_t num_blocks, int64_t envs_per_block,
                          float* node_obs_dev, int64_t out_envs_per_block, int64_t out_env_offset, void* stream) {
@@ -402,7 +456,8 @@ int gmpe_obs_dim(const gmpe_config* c) {
 int gmpe_node_feats(const gmpe_config* c) { return (c->scenario >= GMPE_SCENARIO_ROT_INV || c->graph_feat_type == 1) ? 7 : GMPE_NODE_FEATS; }
 int gmpe_num_entities(const gmpe_config* c) { return c->num_agents + c->num_landmarks + c->num_obstacles; }
 int gmpe_entity_table_width(const gmpe_config* c) {
-    return 2 * gmpe_num_entities(c) + 4 * c->num_agents + (c->scenario >= GMPE_SCENARIO_ROT_INV ? 2 * c->num_agents : 0) + (c->scenario == GMPE_SCENARIO_TWO_PHASE ? 2 : 0);
+    return 2 * gmpe_num_entities(c) + 4 * c->num_agents + (c->scenario >= GMPE_SCENARIO_ROT_INV ? 2 * c->num_agents : 0) + (c->scenario == GMPE_SCENARIO_TWO_PHASE ? 2 : 0) +
+           (gmpe_num_entities(c) + 31) / 32;
 }
 
 static int field_info(const gmpe_handle* h, int f, void** ptr, size_t* bytes) {

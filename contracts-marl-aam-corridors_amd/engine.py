@@ -22,10 +22,12 @@ class StepOutputs(object):
 
 
 class GmpeEngine(object):
-    def __init__(self, cfg, device=0, adj_compact=False, with_info=True, node_form="rows"):
+    def __init__(self, cfg, device=0, adj_compact=False, with_info=True, node_form="rows", adj_form=None):
         """node_form: "rows" — the engine writes node_obs [N,A,E,F] (what GraphSubprocVecEnv hands the runner); "table" — it writes the fp64 entity table
         [N,W] instead (include/gmpe.h gmpe_outputs.entity_table: the state the rows are a pure function of, ~8x fewer bytes — the form a rank ships to the learner,
-        expanded there by expand_node_obs); "both" — both outputs."""
+        expanded there by expand_node_obs); "both" — both outputs.
+        adj_form: None — by `adj_compact` ([N,E,E] or [N,A,E,E]); "none" — no adjacency output at all: the matrix is a function of the entity table too (positions +
+        mask words, expand_adj), so a rank that ships the table need not write or ship it (needs node_form "table" or "both")."""
         if not isinstance(cfg, GmpeConfig):
             raise TypeError("cfg must be a gmpe.config.GmpeConfig")
         self.lib = _lib.load()
@@ -39,6 +41,11 @@ class GmpeEngine(object):
         if node_form not in ("rows", "table", "both"):
             raise ValueError("node_form must be 'rows', 'table' or 'both'")
         self.node_form = node_form
+        if adj_form not in (None, "none"):
+            raise ValueError("adj_form must be None (by adj_compact) or 'none'")
+        if adj_form == "none" and node_form == "rows":
+            raise ValueError("adj_form='none' needs the entity table (node_form 'table' or 'both'): the adjacency is rebuilt from it")
+        self.adj_form = "none" if adj_form == "none" else ("compact" if adj_compact else "full")
         self.h = C.c_void_p()
         _lib.check(self.lib.gmpe_create(C.byref(cfg), self.device.index, C.byref(self.h)), "gmpe_create")
         N, A, E, D = self.N, self.A, self.E, self.D
@@ -48,7 +55,7 @@ class GmpeEngine(object):
             agent_id=torch.empty((N, A, 1), dtype=torch.int32, device=dev),
             node_obs=torch.empty((N, A, E, cfg.node_feats), dtype=torch.float32, device=dev) if node_form != "table" else None,
             entity_table=torch.empty((N, cfg.entity_table_width), dtype=torch.float64, device=dev) if node_form != "rows" else None,
-            adj=torch.empty((N, E, E) if adj_compact else (N, A, E, E), dtype=torch.float32, device=dev),
+            adj=None if adj_form == "none" else torch.empty((N, E, E) if adj_compact else (N, A, E, E), dtype=torch.float32, device=dev),
             reward=torch.empty((N, A), dtype=torch.float32, device=dev),
             done=torch.empty((N, A), dtype=torch.uint8, device=dev),
             info=torch.empty((N, A, len(INFO_KEYS)), dtype=torch.float32, device=dev) if with_info else None)
@@ -152,6 +159,13 @@ class GmpeEngine(object):
         """K steps in ONE launch (gmpe_rollout_steps, the persistent rollout kernel). Step k reads action_sets[k % S] and writes
         output slot (first_slot + k) % num_slots: `slot0` = StepOutputs of slot 0 (default: the engine's own buffers),
         `strides` = dict output-name -> elements between consecutive slots (default 0). Bit-identical to `num_steps` step() calls."""
+        self.prepare_rollout(action_sets, num_steps, slot0, num_slots, first_slot, strides, masks, active_masks)()
+        return self.out
+
+    def prepare_rollout(self, action_sets, num_steps, slot0=None, num_slots=1, first_slot=0, strides=None, masks=None, active_masks=None):
+        """The launch of rollout(...) with these arguments as a callable: the argument structs (gmpe_rollout, gmpe_outputs) are built once, a call is ONE C call
+        (gmpe_rollout_steps on the current stream). For collect loops that launch the same rollout every episode — building slot views and structs in Python costs
+        ~30 us per launch, 7 % of a 20-step rollout at c2. The tensors are referenced, not copied: their contents are read / written at launch time."""
         a = action_sets
         self._check_action_sets(a)
         o = self._o if slot0 is None else self._pack(slot0)
@@ -161,8 +175,12 @@ class GmpeEngine(object):
                              int(st.get("reward", 0)), int(st.get("done", 0)), int(st.get("info", 0)), int(st.get("masks", 0)),
                              None if masks is None else masks.data_ptr(), None if active_masks is None else active_masks.data_ptr(),
                              int(st.get("entity_table", 0)))
-        _lib.check(self.lib.gmpe_rollout_steps(self.h, a.data_ptr(), C.byref(r), C.byref(o), self._stream()), "gmpe_rollout_steps")
-        return self.out
+        keep = (a, slot0, masks, active_masks)                           # the tensors behind the raw pointers stay alive with the callable
+        fn, h, ap, rp, op, stream, check = self.lib.gmpe_rollout_steps, self.h, a.data_ptr(), C.byref(r), C.byref(o), self._stream, _lib.check
+
+        def launch(_keep=keep, _r=r, _o=o):
+            check(fn(h, ap, rp, op, stream()), "gmpe_rollout_steps")
+        return launch
 
     def tuning(self):
         """What gmpe_create chose (tile shape, store flavour, split / rollout paths) as a dict."""
@@ -311,6 +329,10 @@ class GmpeEngine(object):
         """node_obs rows from entity tables, bit-identical to what the engine writes (gmpe_expand_node_obs; module-level `expand_node_obs` needs no engine)."""
         return expand_node_obs(self.cfg, table, out=out, out_envs=out_envs, env_offset=env_offset)
 
+    def expand_adj(self, table, copies=1, out=None, out_envs=None, env_offset=0):
+        """The adjacency of every env-step from its entity table, bit-identical to the engine's own output (gmpe_expand_adj)."""
+        return expand_adj(self.cfg, table, copies=copies, out=out, out_envs=out_envs, env_offset=env_offset)
+
     def masks_from_dones(self, done, masks, active_masks):
         """masks / active_masks (f32 [N,A,...], contiguous, N*A elements) from a uint8 [N,A] done tensor, one tiny kernel."""
         _lib.check(self.lib.gmpe_masks_from_dones(self.h, done.data_ptr(), masks.data_ptr() if masks is not None else None,
@@ -359,4 +381,26 @@ def expand_node_obs(cfg, table, out=None, out_envs=None, env_offset=0):
     if blocks and n:
         _lib.check(lib.gmpe_expand_node_obs(C.byref(cfg), table.device.index, table.data_ptr(), blocks, n, out.data_ptr(), out_envs, int(env_offset),
                                             C.c_void_p(torch.cuda.current_stream(table.device).cuda_stream)), "gmpe_expand_node_obs")
+    return out
+
+
+def expand_adj(cfg, table, copies=1, out=None, out_envs=None, env_offset=0):
+    """float64 entity tables [..., n, W] -> adjacency float32 [..., out_envs, E, E] (copies = 1) or [..., out_envs, copies, E, E] (copies = A: the materialised
+    per-agent form), rows of the table's n envs written at env_offset .. env_offset + n of every block. f32(sqrt(dx^2 + dy^2)) with the engine's own expression and
+    this step's mask words: bit-identical to the adjacency the engine writes (gmpe_step.hip k_adj_from_table). No handle needed."""
+    lib = _lib.load()
+    if table.dtype != torch.float64 or not table.is_contiguous() or not table.is_cuda or table.dim() < 2 or table.shape[-1] != cfg.entity_table_width:
+        raise ValueError("table must be a contiguous float64 device tensor [..., n, %d]" % cfg.entity_table_width)
+    n = int(table.shape[-2])
+    blocks = int(table.numel() // (n * table.shape[-1])) if n else 0
+    out_envs = n if out_envs is None else int(out_envs)
+    E = cfg.num_entities
+    shape = tuple(table.shape[:-2]) + ((out_envs, E, E) if copies == 1 else (out_envs, int(copies), E, E))
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=table.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != table.device:
+        raise ValueError("out must be a contiguous float32 tensor of shape %s on %s" % (shape, table.device))
+    if blocks and n:
+        _lib.check(lib.gmpe_expand_adj(C.byref(cfg), table.device.index, table.data_ptr(), blocks, n, out.data_ptr(), out_envs, int(env_offset), int(copies),
+                                       C.c_void_p(torch.cuda.current_stream(table.device).cuda_stream)), "gmpe_expand_adj")
     return out

@@ -14,7 +14,7 @@ from .config import NODE_FEATS
 from .engine import StepOutputs
 
 
-def storage_spec(cfg, episode_length, adj_compact, node_form):
+def storage_spec(cfg, episode_length, adj_compact, node_form, with_adj=True):
     """name -> (dtype, shape) of the env-side arrays of a rollout (graph_buffer.py:84-164 shapes). With node_form "table" the node features are kept as the fp64
     entity table [T+1, N, W] they are a pure function of (include/gmpe.h gmpe_outputs.entity_table) instead of the [T+1, N, A, E, F] rows."""
     N, A, E, D = cfg.num_envs, cfg.num_agents, cfg.num_entities, cfg.obs_dim
@@ -25,7 +25,8 @@ def storage_spec(cfg, episode_length, adj_compact, node_form):
         spec["node_obs"] = (f32, (T1, N, A, E, cfg.node_feats))
     if node_form != "rows":
         spec["entity_table"] = (torch.float64, (T1, N, cfg.entity_table_width))
-    spec["_adj"] = (f32, (T1, N, E, E) if adj_compact else (T1, N, A, E, E))
+    if with_adj:
+        spec["_adj"] = (f32, (T1, N, E, E) if adj_compact else (T1, N, A, E, E))
     spec["agent_id"] = (torch.int32, (T1, N, A, 1))
     spec["rewards"] = (f32, (T, N, A, 1))
     spec["dones"] = (torch.uint8, (T, N, A))
@@ -44,7 +45,9 @@ class DeviceRolloutBuffer(object):
         c, dev = engine.cfg, engine.device
         self.node_form = getattr(engine, "node_form", "rows")
         storage = dict(storage or {})
-        for name, (dt, shape) in storage_spec(c, self.T, engine.adj_compact, self.node_form).items():
+        self.adj_form = getattr(engine, "adj_form", "compact" if engine.adj_compact else "full")
+        self._adj = None
+        for name, (dt, shape) in storage_spec(c, self.T, engine.adj_compact, self.node_form, with_adj=self.adj_form != "none").items():
             t = storage.pop(name, None)
             if t is None:
                 t = (torch.ones if name in ("masks", "active_masks") else torch.zeros)(shape, dtype=dt, device=dev)
@@ -61,6 +64,7 @@ class DeviceRolloutBuffer(object):
             self.entity_table = None
         self.info = torch.zeros_like(engine.out.info) if engine.out.info is not None else None
         self.step = 0
+        self._prepared = {}
 
     @property
     def node_obs(self):
@@ -73,7 +77,12 @@ class DeviceRolloutBuffer(object):
     # ------------------------------------------------------------------ views with the reference's shapes
     @property
     def adj(self):
-        """[T+1, N, A, E, E]; a zero-copy broadcast when the engine writes the compact matrix."""
+        """[T+1, N, A, E, E]; a zero-copy broadcast when the engine writes the compact matrix; rebuilt from the entity tables (gmpe_expand_adj, bit-identical) when
+        the engine writes no adjacency at all (adj_form 'none')."""
+        if self._adj is None:
+            a = self.engine.expand_adj(self.entity_table)
+            T1, N, E, _ = a.shape
+            return a[:, :, None].expand(T1, N, self.engine.A, E, E)
         if self.engine.adj_compact:
             T1, N, E, _ = self._adj.shape
             return self._adj[:, :, None].expand(T1, N, self.engine.A, E, E)
@@ -98,7 +107,7 @@ class DeviceRolloutBuffer(object):
     def _bind(self, slot, reward_slot):
         e = self.engine
         o = StepOutputs(obs=self.obs[slot], agent_id=self.agent_id[slot], node_obs=None if self._node_obs is None else self._node_obs[slot],
-                        entity_table=None if self.entity_table is None else self.entity_table[slot], adj=self._adj[slot],
+                        entity_table=None if self.entity_table is None else self.entity_table[slot], adj=None if self._adj is None else self._adj[slot],
                         reward=self.rewards[reward_slot].view(e.N, e.A) if reward_slot is not None else e.out.reward,
                         done=self.dones[reward_slot] if reward_slot is not None else e.out.done, info=self.info)
         e.rebind(o)
@@ -129,6 +138,8 @@ class DeviceRolloutBuffer(object):
         if self._node_obs is None:
             raise ValueError("insert_external takes node_obs rows: the buffer's engine must keep them (node_form 'rows' or 'both')")
         put(self.obs[t + 1], obs); put(self.agent_id[t + 1], agent_id); put(self._node_obs[t + 1], node_obs)
+        if self._adj is None:
+            raise ValueError("insert_external takes an adjacency: the buffer's engine must keep one (adj_form not 'none')")
         a = torch.as_tensor(adj)
         if e.adj_compact and a.dim() == 4:
             a = a[:, 0]                                   # the A per-agent matrices are one matrix (…_july.py:1625)
@@ -150,14 +161,30 @@ class DeviceRolloutBuffer(object):
                 self.insert_step(action_sets[k % action_sets.shape[0]])
             return e.out
         NA = e.N * e.A
+        key = (action_sets.data_ptr(), int(action_sets.shape[0]), K, self.step)
+        launch = self._prepared.get(key) if hasattr(e, "prepare_rollout") else None
+        if launch is not None:                                   # the same rollout as an earlier call: one C call, no views / structs rebuilt (engine.prepare_rollout)
+            launch[0]()
+            last = (self.step + K - 1) % self.T
+            self._bind(last + 1, last)
+            self.step = (self.step + K) % self.T
+            return e.out
         slot0 = StepOutputs(obs=self.obs[1], agent_id=self.agent_id[1], node_obs=None if self._node_obs is None else self._node_obs[1],
-                            entity_table=None if self.entity_table is None else self.entity_table[1], adj=self._adj[1],
+                            entity_table=None if self.entity_table is None else self.entity_table[1], adj=None if self._adj is None else self._adj[1],
                             reward=self.rewards[0].view(e.N, e.A), done=self.dones[0], info=self.info)
         strides = dict(obs=self.obs[0].numel(), agent_id=NA, node_obs=0 if self._node_obs is None else self._node_obs[0].numel(),
-                       entity_table=0 if self.entity_table is None else self.entity_table[0].numel(), adj=self._adj[0].numel(),
+                       entity_table=0 if self.entity_table is None else self.entity_table[0].numel(), adj=0 if self._adj is None else self._adj[0].numel(),
                        reward=NA, done=NA, info=0, masks=NA)
-        e.rollout(action_sets, K, slot0=slot0, num_slots=self.T, first_slot=self.step, strides=strides,
-                  masks=self.masks[1], active_masks=self.active_masks[1])
+        if hasattr(e, "prepare_rollout"):
+            launch = e.prepare_rollout(action_sets, K, slot0=slot0, num_slots=self.T, first_slot=self.step, strides=strides,
+                                       masks=self.masks[1], active_masks=self.active_masks[1])
+            if len(self._prepared) >= 8:
+                self._prepared.clear()
+            self._prepared[key] = (launch, action_sets)         # keeps the action tensor alive: its address is part of the key
+            launch()
+        else:
+            e.rollout(action_sets, K, slot0=slot0, num_slots=self.T, first_slot=self.step, strides=strides,
+                      masks=self.masks[1], active_masks=self.active_masks[1])
         # the engine's "current outputs" are the last slot written, as after insert_step
         last = (self.step + K - 1) % self.T
         self._bind(last + 1, last)

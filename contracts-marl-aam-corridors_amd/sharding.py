@@ -145,13 +145,16 @@ class RolloutGather(object):
 _ROLLOUT_SECTIONS = ("obs", "entity_table", "_adj", "rewards", "dones", "masks", "active_masks")     # agent_id is arange(A): regenerated by the learner, not shipped
 
 
-def rollout_slab_layout(cfg, episode_length):
-    """Byte layout of one rank's rollout slab: the env-side arrays of a T-step rollout (rollout.storage_spec, compact adjacency, node features as the fp64 entity
-    table) back to back, every section 16-byte aligned. -> ({name: (offset, nbytes, dtype, shape)}, total bytes)."""
+def rollout_slab_layout(cfg, episode_length, with_adj=True):
+    """Byte layout of one rank's rollout slab: the env-side arrays of a T-step rollout (rollout.storage_spec, node features as the fp64 entity table, and — unless the
+    engine writes no adjacency at all (adj_form 'none': the matrix is rebuilt from the table on the learner) — one ExE adjacency per env) back to back, every section
+    16-byte aligned. -> ({name: (offset, nbytes, dtype, shape)}, total bytes)."""
     from .rollout import storage_spec
-    spec = storage_spec(cfg, episode_length, adj_compact=True, node_form="table")
+    spec = storage_spec(cfg, episode_length, adj_compact=True, node_form="table", with_adj=with_adj)
     off, out = 0, {}
     for name in _ROLLOUT_SECTIONS:
+        if name not in spec:
+            continue
         dt, shape = spec[name]
         n = 1
         for s in shape:
@@ -169,14 +172,15 @@ def rollout_slab_views(slab, layout):
 
 def rollout_bytes_per_env_step(cfg, episode_length=25, form="compact"):
     """Bytes a rank ships per env-step. form: "rows" = the round-3 slab (obs + node_obs rows + one ExE adj + reward + done), "compact" = this
-    module's rollout slab (obs + entity table + one ExE adj + reward + done + masks), "materialised" = what GraphSubprocVecEnv's workers pickle (A adjacency copies)."""
+    module's rollout slab (obs + entity table + one ExE adj + reward + done + masks), "table" = the same without the adjacency (adj_form 'none': rebuilt from the table
+    on the learner), "materialised" = what GraphSubprocVecEnv's workers pickle (A adjacency copies)."""
     A, E, D, F, W = cfg.num_agents, cfg.num_entities, cfg.obs_dim, cfg.node_feats, cfg.entity_table_width
     if form == "rows":
         return 4 * A * D + 4 * A * E * F + 4 * E * E + 4 * A + A
     if form == "materialised":
         return 4 * A * D + 4 * A * E * F + 4 * A * E * E + 4 * A + A
     T = float(episode_length)
-    return (4 * A * D + 8 * W + 4 * E * E + 8 * A) * (T + 1) / T + 4 * A + A
+    return (4 * A * D + 8 * W + (4 * E * E if form == "compact" else 0) + 8 * A) * (T + 1) / T + 4 * A + A
 
 
 class ShardedRolloutCollector(object):
@@ -187,10 +191,12 @@ class ShardedRolloutCollector(object):
     * Launch shape: `DeviceRolloutBuffer.collect` = one launch of the persistent rollout kernel per T steps (the headline launch shape), writing straight into the slab.
     * Slab: obs + the fp64 ENTITY TABLE (the per-entity state node_obs is a pure function of: ~8x fewer bytes than the [A,E,F] rows) + one ExE adjacency per env +
       rewards / dones / masks; the learner rebuilds the node rows bit for bit with gmpe_expand_node_obs straight into its global [T+1, world*N, A, E, F] array.
+      With an engine created with adj_form="none" the adjacency is not shipped either (it is a function of the table's positions + mask words: gmpe_expand_adj) —
+      the slab is then obs + table + rewards / dones / masks, 1.5 KB per env-step at c2 / c3 instead of 8.6-8.8 KB of rows.
     * Two slabs alternate: the gather of rollout k runs on RCCL's stream while rollout k+1 is collected (slot 0 of the next rollout is carried over first).
     Every rank must hold the same number of envs. The engine must be created with adj_compact=True, node_form="table"."""
 
-    def __init__(self, engine, episode_length, world, rank=None, group=None, dst=0, expand=None):
+    def __init__(self, engine, episode_length, world, rank=None, group=None, dst=0, expand=None, expand_adj=None):
         import torch.distributed as dist
         from .rollout import DeviceRolloutBuffer
         if not engine.adj_compact or getattr(engine, "node_form", "rows") != "table":
@@ -199,7 +205,8 @@ class ShardedRolloutCollector(object):
         self.engine, self.world, self.T = engine, int(world), int(episode_length)
         self.rank = dist.get_rank(group) if rank is None else int(rank)
         self.cfg = engine.cfg
-        self.layout, self.slab_bytes = rollout_slab_layout(self.cfg, self.T)
+        self.with_adj = getattr(engine, "adj_form", "compact") != "none"
+        self.layout, self.slab_bytes = rollout_slab_layout(self.cfg, self.T, self.with_adj)
         dev = engine.device
         n = torch.tensor([self.cfg.num_envs], dtype=torch.int64, device=dev if dist.get_backend(group) == "nccl" else "cpu")
         lo, hi = n.clone(), n.clone()
@@ -212,7 +219,7 @@ class ShardedRolloutCollector(object):
         self._work = [None, None]
         self._flip = 0
         self._last = None
-        self._expand = expand
+        self._expand, self._expand_adj = expand, expand_adj
 
     def warmup(self):
         """GMPERunner.warmup (graph_mpe_runner.py:213-238): the reset observations go to slot 0 of the first rollout."""
@@ -263,6 +270,8 @@ class ShardedRolloutCollector(object):
                 out[name] = torch.empty(shape, dtype=dt, device=dev)
             return out[name]
         for name, key in (("obs", "obs"), ("adj", "_adj"), ("rewards", "rewards"), ("masks", "masks"), ("active_masks", "active_masks")):
+            if key not in self.layout:
+                continue
             _, _, dt, shape = self.layout[key]
             dst = dest(name, dt, (shape[0], Wd * N) + shape[2:])
             for r in range(Wd):
@@ -277,6 +286,13 @@ class ShardedRolloutCollector(object):
             from .engine import expand_node_obs as expand
         for r in range(Wd):
             expand(c, per[r]["entity_table"].contiguous(), out=node, out_envs=Wd * N, env_offset=r * N)
+        if not self.with_adj:                                        # the adjacency was not shipped: rebuild it from the tables (bit-identical, gmpe_expand_adj)
+            adj = dest("adj", torch.float32, (T1, Wd * N, E, E))
+            expand_a = self._expand_adj
+            if expand_a is None:
+                from .engine import expand_adj as expand_a
+            for r in range(Wd):
+                expand_a(c, per[r]["entity_table"].contiguous(), out=adj, out_envs=Wd * N, env_offset=r * N)
         if "agent_id" not in out:
             out["agent_id"] = torch.arange(A, dtype=torch.int32, device=dev).view(1, 1, A, 1).expand(T1, Wd * N, A, 1)
         return out

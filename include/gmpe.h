@@ -190,7 +190,8 @@ typedef struct gmpe_outputs {
                             what a rank SHIPS instead of the [N,A,E,F] rows (SURVEY §8e "state + one E×E per env"); gmpe_expand_node_obs rebuilds the rows
                             bit for bit on the learner. Layout per env: x[E], y[E] of every entity (agents after the move / after a reset), then per agent
                             vox[A], voy[A] (velocity BEFORE this step's reward loop), vnx[A], vny[A] (AFTER it: re-drawn heading on a goal reach, core.py:324-333);
-                            rot_inv family: + cos[A], sin[A] of the post-reward heading; two_phase_graph: + exit x, exit y (its goal node feature)   */
+                            rot_inv family: + cos[A], sin[A] of the post-reward heading; two_phase_graph: + exit x, exit y (its goal node feature); last, ceil(E / 32)
+                            words of this step's adjacency mask (bit k of word k / 32 = node k's rows / columns are zeroed, …_july.py:1627-1648), 32 bits per double   */
 } gmpe_outputs;
 
 int gmpe_abi_version(void);
@@ -200,7 +201,7 @@ const char* gmpe_last_error(void);
 int gmpe_obs_dim(const gmpe_config* cfg);
 int gmpe_node_feats(const gmpe_config* cfg);   /* 8; 7 for the rot_inv family and for graph_feat_type = 1 */
 int gmpe_num_entities(const gmpe_config* cfg);
-int gmpe_entity_table_width(const gmpe_config* cfg);   /* W of gmpe_outputs.entity_table: 2E + 4A (+ 2A rot_inv family) (+ 2 two_phase_graph) doubles per env */
+int gmpe_entity_table_width(const gmpe_config* cfg);   /* W of gmpe_outputs.entity_table: 2E + 4A (+ 2A rot_inv family) (+ 2 two_phase_graph) + ceil(E / 32) doubles per env */
 
 /* Create the engine on HIP device `device`. Replaces N x `GraphMPEEnv(args)` + `env.seed(seed +
  * rank*1000)` (multiagent/MPE_env.py:56-84, onpolicy/scripts/train_mpe.py:21-43). */
@@ -329,6 +330,11 @@ int gmpe_edges_from_adj_compact(gmpe_handle* h, const float* adj_compact_dev, in
  *   node_obs_dev  f32 [num_blocks, out_envs_per_block, A, E, F]  block t, env n -> out env out_env_offset + n (a rank's env range inside the global batch) */
 int gmpe_expand_node_obs(const gmpe_config* cfg, int device, const double* table_dev, int64_t num_blocks, int64_t envs_per_block,
                          float* node_obs_dev, int64_t out_envs_per_block, int64_t out_env_offset, void* stream);
+/* The same for the adjacency: the E x E matrix of every env-step from its entity table (positions + mask words) — f32(sqrt(dx^2 + dy^2)) with the engine's own
+ * expression (World.calculate_distances, core.py:600-624), masked rows / columns zeroed (…_july.py:1627-1648) — bit-identical to gmpe_outputs.adj, so a rank need not
+ * ship the matrix at all. adj_dev: f32 [num_blocks, out_envs_per_block, copies, E, E]; copies = 1: the compact form, copies = A: the materialised [.., A, E, E]. */
+int gmpe_expand_adj(const gmpe_config* cfg, int device, const double* table_dev, int64_t num_blocks, int64_t envs_per_block,
+                    float* adj_dev, int64_t out_envs_per_block, int64_t out_env_offset, int32_t copies, void* stream);
 
 /* Rollout-buffer masks from a step's dones (GraphReplayBuffer.insert: onpolicy/utils/graph_buffer.py:223-251 with the runner's
  * rules graph_mpe_runner.py:85-90, 395-405): masks f32 [N,A] = 0 where done; active_masks f32 [N,A] = 0 where done unless all agents of

@@ -108,7 +108,8 @@ static inline int is_tube(const gmpe_config* c) { return c->scenario != GMPE_SCE
 int gmpo_num_entities(const gmpe_config* c) { return c->num_agents + c->num_landmarks + c->num_obstacles; }
 /* width of the entity table (include/gmpe.h gmpe_outputs.entity_table): x[E], y[E], vox / voy / vnx / vny [A] (+ cos / sin [A] rot_inv family) (+ exit x, y two_phase) */
 int gmpo_entity_table_width(const gmpe_config* c) {
-    return 2 * gmpo_num_entities(c) + 4 * c->num_agents + (is_rotfam(c) ? 2 * c->num_agents : 0) + (c->scenario == GMPE_SCENARIO_TWO_PHASE ? 2 : 0);
+    return 2 * gmpo_num_entities(c) + 4 * c->num_agents + (is_rotfam(c) ? 2 * c->num_agents : 0) + (c->scenario == GMPE_SCENARIO_TWO_PHASE ? 2 : 0) +
+           (gmpo_num_entities(c) + 31) / 32;
 }
 
 /* ------------------------------------------------------------------ create / fields */
@@ -267,7 +268,20 @@ static void table_stage(envv* v, int stage) {
     } else {
         for (int a = 0; a < A; ++a) agent_vel(v, a, &vn[a], &vn[A + a]);
         if (is_rotfam(&h->c)) for (int a = 0; a < A; ++a) { vn[2 * A + a] = cos(v->s2[a]); vn[3 * A + a] = sin(v->s2[a]); }
-        if (h->c.scenario == GMPE_SCENARIO_TWO_PHASE) { T[h->W - 2] = v->tube[T_EXX]; T[h->W - 1] = v->tube[T_EXY]; }
+        const int nmw = (E + 31) / 32;
+        if (h->c.scenario == GMPE_SCENARIO_TWO_PHASE) { T[h->W - nmw - 2] = v->tube[T_EXX]; T[h->W - nmw - 1] = v->tube[T_EXY]; }
+        /* adjacency mask of this step (graph_observation's `mask:` block above: done agents, reached landmarks), 32 node bits per double */
+        for (int j = 0; j < nmw; ++j) {
+            uint32_t bits = 0;
+            for (int b = 0; b < 32 && 32 * j + b < E; ++b) {
+                const int k = 32 * j + b;
+                int off = 0;
+                if (k < A) off = v->status[k];
+                else if (k < A + v->L) { for (int a = 0; a < A; ++a) if (v->goal_tracker[a] == k - A) off = 1; }
+                bits |= (uint32_t)(off ? 1 : 0) << b;
+            }
+            T[h->W - nmw + j] = (double)bits;
+        }
     }
 }
 

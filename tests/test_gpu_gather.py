@@ -35,7 +35,7 @@ def _queue(orc, targets, rng, N, A):
 @pytest.mark.parametrize("scen", SCENS)
 def test_expand_node_obs_is_bit_identical_to_the_engines_rows(scen, feat):
     import torch
-    from gmpe.engine import GmpeEngine, expand_node_obs
+    from gmpe.engine import GmpeEngine, expand_adj, expand_node_obs
     nav = scen == "navigation_graph"
     N, A = 37, 4
     kw = dict(scenario_name=scen, num_envs=N, num_agents=A, world_size=2.4, episode_length=(8 if nav else 30), seed=91, graph_feat_type=feat)
@@ -49,10 +49,11 @@ def test_expand_node_obs_is_bit_identical_to_the_engines_rows(scen, feat):
     tab_o = np.zeros((N, W)); orc.lib.gmpo_get_entity_table(orc.h, tab_o.ctypes.data)
     np.testing.assert_allclose(_np(o.entity_table), tab_o, rtol=0, atol=1e-9)
     assert torch.equal(expand_node_obs(cfg, o.entity_table), o.node_obs)
+    assert torch.equal(expand_adj(cfg, o.entity_table, copies=A), o.adj)
     rng = np.random.RandomState(4)
     if not nav:
         _queue(orc, (eng, orc), rng, N, A)
-    redraws = 0
+    redraws, masked_rows = 0, 0
     for t in range(60):
         act = (rng.randint(0, cfg.n_actions, (N, A)) if nav else np.where(rng.rand(N, A) < 0.7, 14, rng.randint(0, 25, (N, A)))).astype(np.int32)
         st_before = eng.get("status").copy()
@@ -62,9 +63,14 @@ def test_expand_node_obs_is_bit_identical_to_the_engines_rows(scen, feat):
         rows = expand_node_obs(cfg, o.entity_table)
         assert torch.equal(rows, o.node_obs), "t=%d: expanded rows differ from the engine's" % t
         np.testing.assert_allclose(_np(rows), oo[2], rtol=0, atol=1e-5)
+        # the adjacency from the same table (positions + this step's mask words): the engine's own matrix bit for bit, masked rows included
+        adj1 = expand_adj(cfg, o.entity_table)
+        assert torch.equal(adj1, o.adj[:, 0]) and torch.equal(expand_adj(cfg, o.entity_table, copies=A), o.adj), "t=%d: expanded adjacency differs" % t
+        masked_rows += int((_np(adj1).sum(axis=2) == 0).sum())
         redraws += int((eng.get("status").astype(bool) & ~st_before.astype(bool) & ~oo[7][:, None]).sum())
     if not nav:
         assert redraws >= 10                                        # newly-finished agents: ego i saw agent k's re-drawn velocity iff k <= i
+        assert masked_rows >= 10                                    # ... and their rows / columns of the adjacency were zeroed
     # offset form: the rows of this rank's envs written into a larger global array
     big = torch.zeros((N + 9, A, cfg.num_entities, cfg.node_feats), device="cuda")
     expand_node_obs(cfg, o.entity_table, out=big, out_envs=N + 9, env_offset=5)
@@ -100,8 +106,32 @@ def test_rollout_buffer_table_form_equals_rows_form(scen):
     assert torch.equal(b2.node_obs[:2], b1.node_obs[:2])
 
 
+def test_expand_adj_odd_entity_count_and_64_agents():
+    """E*E not a multiple of 4 (scalar path) and E = 128 (four mask words): expand_adj == the engine's adjacency."""
+    import torch
+    from gmpe.engine import GmpeEngine, expand_adj
+    for kw in (dict(scenario_name="navigation_graph", num_envs=20, num_agents=3, num_obstacles=1, world_size=3.0, episode_length=7, seed=26),
+               dict(scenario_name=JULY, num_envs=3, num_agents=64, world_size=30.0, episode_length=4, seed=23)):
+        cfg = gmpe.make_config(**kw)
+        eng = GmpeEngine(cfg, node_form="both", adj_compact=True)
+        o = eng.reset()
+        assert torch.equal(expand_adj(cfg, o.entity_table), o.adj)
+        g = torch.Generator(); g.manual_seed(1)
+        for t in range(9):
+            o = eng.step(torch.randint(0, cfg.n_actions, (cfg.num_envs, cfg.num_agents), generator=g, dtype=torch.int32))
+            assert torch.equal(expand_adj(cfg, o.entity_table), o.adj), (kw["num_agents"], t)
+        if cfg.num_agents == 64:                                     # force masks into the upper words: agents 40.. done
+            st = eng.get("status"); st[:, 40:] = 1; eng.set("status", st)
+            gt = eng.get("goal_tracker"); gt[:, 40:] = np.arange(40, 64); eng.set("goal_tracker", gt)
+            o = eng.step(torch.zeros((cfg.num_envs, 64), dtype=torch.int32))
+            a = expand_adj(cfg, o.entity_table)
+            assert torch.equal(a, o.adj) and (a[:, 45] == 0).all() and (a[:, 64 + 45] == 0).all() and (a[:, 3, :40] != 0).any()
+        eng.check_errors()
+
+
+@pytest.mark.parametrize("adj_form", [None, "none"])
 @pytest.mark.parametrize("scen", [JULY, ROTFAM[0], "navigation_graph"])
-def test_sharded_rollout_collector_real_engine_over_rccl(scen):
+def test_sharded_rollout_collector_real_engine_over_rccl(scen, adj_form):
     import torch
     import torch.distributed as dist
     from gmpe.engine import GmpeEngine
@@ -114,9 +144,9 @@ def test_sharded_rollout_collector_real_engine_over_rccl(scen):
     cfg = gmpe.make_config(scenario_name=scen, num_envs=N, num_agents=A, world_size=4.0, episode_length=5, seed=44)
     e_ref = GmpeEngine(cfg, adj_compact=True)
     ref = DeviceRolloutBuffer(e_ref, T)
-    col = ShardedRolloutCollector(GmpeEngine(cfg, adj_compact=True, node_form="table"), T, 1)
+    col = ShardedRolloutCollector(GmpeEngine(cfg, adj_compact=True, node_form="table", adj_form=adj_form), T, 1)
     ref.warmup(); col.warmup()
-    assert col.slab_bytes < 0.45 * (T + 1) * N * rollout_bytes_per_env_step(cfg, T, "rows")       # the compact slab is less than half of the rows-form bytes
+    assert col.slab_bytes < (0.45 if adj_form is None else 0.25) * (T + 1) * N * rollout_bytes_per_env_step(cfg, T, "rows")   # compact: < half of the rows-form bytes; table only: < a quarter
     g = torch.Generator(device="cuda"); g.manual_seed(5)
     for rep in range(3):                                                     # the two slabs alternate; slot 0 is carried from one to the other
         acts = torch.randint(0, cfg.n_actions, (T, N, A), generator=g, device="cuda", dtype=torch.int32)

@@ -203,11 +203,12 @@ class _OracleBackedEngine(object):
     output tensors from the CPU oracle — so the gather path (slab views, rebind, collective, unpack) runs on CPU with the real
     shapes and values of a real config. Test infrastructure only; the GPU twin is tests/test_gpu_vec_env.py::test_rollout_gather_real_engine."""
 
-    def __init__(self, cfg, node_form="rows", do_reset=True):
+    def __init__(self, cfg, node_form="rows", do_reset=True, adj_form=None):
         import torch
         import oracle_lib as ol
         from gmpe.engine import StepOutputs
         self.cfg, self.adj_compact, self.device, self.node_form = cfg, True, torch.device("cpu"), node_form
+        self.adj_form = "none" if adj_form == "none" else "compact"
         N, A, E, D, F = cfg.num_envs, cfg.num_agents, cfg.num_entities, cfg.obs_dim, cfg.node_feats
         self.N, self.A = N, A
         self.orc = ol.Oracle(cfg)
@@ -216,7 +217,7 @@ class _OracleBackedEngine(object):
         self.out = StepOutputs(obs=torch.zeros(N, A, D), agent_id=torch.zeros(N, A, 1, dtype=torch.int32),
                                node_obs=torch.zeros(N, A, E, F) if node_form != "table" else None,
                                entity_table=torch.zeros(N, cfg.entity_table_width, dtype=torch.float64) if node_form != "rows" else None,
-                               adj=torch.zeros(N, E, E), reward=torch.zeros(N, A), done=torch.zeros(N, A, dtype=torch.uint8), info=None)
+                               adj=None if adj_form == "none" else torch.zeros(N, E, E), reward=torch.zeros(N, A), done=torch.zeros(N, A, dtype=torch.uint8), info=None)
 
     def rebind(self, o):
         for k in ("obs", "node_obs", "entity_table", "adj", "reward", "done"):
@@ -231,7 +232,9 @@ class _OracleBackedEngine(object):
     def _fill(self, obs, node, adj):
         import torch
         o = self.out
-        o.obs.copy_(torch.from_numpy(obs)); o.adj.copy_(torch.from_numpy(adj))
+        o.obs.copy_(torch.from_numpy(obs))
+        if o.adj is not None:
+            o.adj.copy_(torch.from_numpy(adj))
         if o.node_obs is not None:
             o.node_obs.copy_(torch.from_numpy(node))
         if o.entity_table is not None:
@@ -347,8 +350,9 @@ def _numpy_expand(cfg, table, out=None, out_envs=None, env_offset=0):
     elif rot:
         cs, sn = T[:, 2 * E + 4 * A:2 * E + 5 * A, None], T[:, 2 * E + 5 * A:2 * E + 6 * A, None]
         two = cfg.scenario == gcfg.SCENARIO_TWO_PHASE
-        gx = (T[:, W - 2, None, None].astype(f32) if two else gxa.astype(f32)) * np.ones((B, A, E), f32)
-        gy = (T[:, W - 1, None, None].astype(f32) if two else gya.astype(f32)) * np.ones((B, A, E), f32)
+        wx = W - (E + 31) // 32 - 2                           # two_phase: exit x, y sit right before the mask words
+        gx = (T[:, wx, None, None].astype(f32) if two else gxa.astype(f32)) * np.ones((B, A, E), f32)
+        gy = (T[:, wx + 1, None, None].astype(f32) if two else gya.astype(f32)) * np.ones((B, A, E), f32)
         rvx = (kvx.astype(f32) - evx.astype(f32)).astype(np.float64); rvy = (kvy.astype(f32) - evy.astype(f32)).astype(np.float64)
         rpx = (kx.astype(f32) - px.astype(f32)).astype(np.float64); rpy = (ky.astype(f32) - py.astype(f32)).astype(np.float64)
         rgx = (gx - px.astype(f32)).astype(np.float64); rgy = (gy - py.astype(f32)).astype(np.float64)
@@ -365,7 +369,30 @@ def _numpy_expand(cfg, table, out=None, out_envs=None, env_offset=0):
     return out
 
 
-def _collector_worker(rank, world, port, q, scen):
+def _numpy_expand_adj(cfg, table, copies=1, out=None, out_envs=None, env_offset=0):
+    """CPU stand-in for gmpe_expand_adj (gloo rehearsal only): f32(sqrt(dx^2 + dy^2)) of pos[min] - pos[max], zero diagonal, masked rows / columns zeroed."""
+    import torch
+    t = table.numpy()
+    E, W = cfg.num_entities, cfg.entity_table_width
+    lead, n = t.shape[:-2], t.shape[-2]
+    T = t.reshape(-1, W)
+    ex, ey = T[:, :E], T[:, E:2 * E]
+    words = T[:, W - (E + 31) // 32:].astype(np.uint64)
+    k = np.arange(E)
+    m = ((words[:, k // 32] >> (k % 32).astype(np.uint64)) & 1).astype(bool)
+    lo, hi = np.minimum(k[:, None], k[None, :]), np.maximum(k[:, None], k[None, :])
+    dx, dy = ex[:, lo] - ex[:, hi], ey[:, lo] - ey[:, hi]
+    d = np.sqrt(dx * dx + dy * dy).astype(np.float32)
+    d[:, k, k] = 0.0
+    d[m[:, :, None] | m[:, None, :]] = 0.0
+    rows = torch.from_numpy(d.reshape(lead + (n, E, E)))
+    if out is None:
+        return rows
+    out[..., env_offset:env_offset + n, :, :] = rows
+    return out
+
+
+def _collector_worker(rank, world, port, q, scen, adj_form=None):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -375,13 +402,14 @@ def _collector_worker(rank, world, port, q, scen):
     NT, A, T = 10, 4, 6
     kw = dict(scenario_name=scen, num_agents=A, world_size=4.0, episode_length=4, seed=8)
     lo, hi = shard_range(NT, world, rank)
-    eng = _OracleBackedEngine(gmpe.make_config(num_envs=hi - lo, env_id_base=lo, **kw), node_form="table", do_reset=False)
+    eng = _OracleBackedEngine(gmpe.make_config(num_envs=hi - lo, env_id_base=lo, **kw), node_form="table", do_reset=False, adj_form=adj_form)
     full = ol.Oracle(gmpe.make_config(num_envs=NT, **kw))
-    col = ShardedRolloutCollector(eng, T, world, expand=_numpy_expand)
+    col = ShardedRolloutCollector(eng, T, world, expand=_numpy_expand, expand_adj=_numpy_expand_adj)
+    ok0 = ("_adj" in col.layout) == (adj_form != "none")
     col.warmup()
     r0 = full.reset()
     rng = np.random.RandomState(2)
-    ok = True
+    ok = ok0
     F = eng.cfg.node_feats
     prev_last = None
     for rep in range(3):                                      # slabs alternate, slot 0 carried across; auto-resets inside every rollout
@@ -410,15 +438,17 @@ def _collector_worker(rank, world, port, q, scen):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scen", ["nav_metered_one_goal_graph_rotate_tube_july", "two_phase_graph", "navigation_graph"])
-def test_sharded_rollout_collector_world_size_2_gloo(scen):
-    """Per-rollout gather of the compact slab (obs + entity table + one ExE adj + rewards / dones / masks), two ranks: the learner's unpacked arrays == the unsharded run's
-    [T+1, N, ...] rollout, node rows rebuilt from the tables, over three alternating slabs. Replaces env_wrappers.py:996-1004 at rollout granularity."""
+@pytest.mark.parametrize("scen,adj_form", [("nav_metered_one_goal_graph_rotate_tube_july", None), ("two_phase_graph", None), ("navigation_graph", None),
+                                           ("nav_metered_one_goal_graph_rotate_tube_july", "none"), ("nav_graph_metered_single_corridor_rot_inv", "none"), ("navigation_graph", "none")])
+def test_sharded_rollout_collector_world_size_2_gloo(scen, adj_form):
+    """Per-rollout gather of the compact slab (obs + entity table + one ExE adj + rewards / dones / masks — or, adj_form 'none', without the adjacency, which the learner
+    rebuilds from the table), two ranks: the learner's unpacked arrays == the unsharded run's [T+1, N, ...] rollout, over three alternating slabs. Replaces
+    env_wrappers.py:996-1004 at rollout granularity."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29100 + (os.getpid() % 2000) + (hash(scen) % 50)
-    ps = [ctx.Process(target=_collector_worker, args=(r, 2, port, q, scen)) for r in range(2)]
+    port = 29100 + (os.getpid() % 2000) + (hash((scen, adj_form)) % 50)
+    ps = [ctx.Process(target=_collector_worker, args=(r, 2, port, q, scen, adj_form)) for r in range(2)]
     [p.start() for p in ps]
     res = sorted(q.get(timeout=240) for _ in range(2))
     [p.join(60) for p in ps]
@@ -432,8 +462,12 @@ def test_rollout_slab_is_compact():
     rows, compact = rollout_bytes_per_env_step(c3, 25, "rows"), rollout_bytes_per_env_step(c3, 25, "compact")
     assert rows == 8810 and compact < 3300 and rows / compact > 2.6
     lay, total = rollout_slab_layout(c3, 25)
-    assert total % 16 == 0 and all(o % 16 == 0 for o, _, _, _ in lay.values()) and "node_obs" not in lay and lay["entity_table"][3] == (26, 4096, 80)
+    assert total % 16 == 0 and all(o % 16 == 0 for o, _, _, _ in lay.values()) and "node_obs" not in lay and lay["entity_table"][3] == (26, 4096, 81)
     assert abs(total / (25 * 4096) - compact) < 8
+    # adj_form 'none': the adjacency is rebuilt on the learner from the table's positions + mask words, the slab drops it
+    table_only = rollout_bytes_per_env_step(c3, 25, "table")
+    lay2, total2 = rollout_slab_layout(c3, 25, with_adj=False)
+    assert "_adj" not in lay2 and table_only < 1650 and rows / table_only > 5.3 and abs(total2 / (25 * 4096) - table_only) < 8
 
 
 # ---------------------------------------------------------------- oracle self-consistency (CPU)
