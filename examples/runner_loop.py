@@ -1,8 +1,10 @@
-"""The reference runner's collect loop (onpolicy/runner/shared/graph_mpe_runner.py:57-103) over the batched engine, twice:
+"""The reference runner's collect loop (onpolicy/runner/shared/graph_mpe_runner.py:57-103) over the batched engine, three ways:
 
   (1) drop-in: `BatchedGraphMPEVecEnv` in place of `GraphSubprocVecEnv` — NumPy in, NumPy out, the runner unchanged;
-  (2) device-resident: `DeviceRolloutBuffer` — the env writes straight into the `[T+1, N, A, ...]` rollout arrays in HBM,
-      and the GNN's edge list (`process_adj`, onpolicy/algorithms/utils/gnn_new.py:329-358) is built on the device.
+  (2) device-resident, open loop: `DeviceRolloutBuffer.collect` — ONE launch writes the whole `[T+1, N, A, ...]` rollout in HBM,
+      and the GNN's edge list (`process_adj`, onpolicy/algorithms/utils/gnn_new.py:329-358) is built on the device;
+  (3) device-resident, policy in the loop: the policy reads slot `step` of the buffer as device tensors and `insert_step` writes slot `step + 1`
+      in place — the runner change of INTEGRATION.md §7 (no NumPy one-hot up, no seven arrays down per step).
 
 The policy is a stand-in (uniform random actions): the learner is outside this package's scope.
 
@@ -74,6 +76,33 @@ def device_loop(args, episodes, max_edge_dist=1.0):
                 masks_zero=int((buf.masks == 0).sum()))
 
 
+def device_closed_loop(args, episodes):
+    """Policy in the loop without leaving the GPU: GMPERunner.collect's inputs are slot `step` of the device buffer, its integer actions
+    go straight into `insert_step`. The stand-in policy is one linear layer on `obs` (the learner is out of scope); what matters is the data flow."""
+    import torch
+    from gmpe.engine import GmpeEngine
+    from gmpe.rollout import DeviceRolloutBuffer
+    from gmpe.config import config_from_args
+    cfg = config_from_args(args)
+    eng = GmpeEngine(cfg, adj_compact=True)
+    buf = DeviceRolloutBuffer(eng, args.episode_length)
+    buf.warmup()                                                                 # GMPERunner.warmup, :213-238
+    T, N, A = args.episode_length, cfg.num_envs, cfg.num_agents
+    torch.manual_seed(0)
+    head = torch.nn.Linear(cfg.obs_dim, cfg.n_actions).to(eng.device)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    with torch.no_grad():
+        for ep in range(episodes):
+            for step in range(T):
+                logits = head(buf.obs[step])                                     # [N, A, n_act] from the slot the env wrote: device tensors, no host hop
+                action = torch.distributions.Categorical(logits=logits).sample() # policy.get_actions' sampled action (:346-355)
+                buf.insert_step(action.to(torch.int32))                          # envs.step + buffer.insert (:82-83, :384-428): slot step+1 written in place
+            buf.after_update()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    return dict(path="device-resident, policy in the loop", env_steps_per_s=N * episodes * T / dt, mean_step_reward=float(buf.rewards.mean()),
+                shapes=dict(obs=tuple(buf.obs.shape), node_obs=tuple(buf.node_obs.shape), adj=tuple(buf.adj.shape)))
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=4096)
@@ -83,7 +112,7 @@ def main(argv=None):
     ap.add_argument("--scenario", default="nav_metered_one_goal_graph_rotate_tube_july")
     a = ap.parse_args(argv)
     args = reference_args(a.envs, a.agents, a.episode_length, a.scenario)
-    out = [drop_in_loop(args, a.episodes), device_loop(args, a.episodes)]
+    out = [drop_in_loop(args, a.episodes), device_loop(args, a.episodes), device_closed_loop(args, a.episodes)]
     for r in out:
         print(r)
     return out

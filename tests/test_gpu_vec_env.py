@@ -290,6 +290,7 @@ def test_example_runner_loop_runs_both_paths():
     import os
     spec = importlib.util.spec_from_file_location("runner_loop", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "runner_loop.py"))
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
-    a, b = mod.main(["--envs", "48", "--agents", "4", "--episode-length", "8", "--episodes", "2"])
+    a, b, c = mod.main(["--envs", "48", "--agents", "4", "--episode-length", "8", "--episodes", "2"])
+    assert c["shapes"]["obs"] == (9, 48, 4, 19) and c["env_steps_per_s"] > 0 and np.isfinite(c["mean_step_reward"])   # policy in the loop on device tensors
     assert a["shapes"]["adj"] == (48, 4, 8, 8) and a["info_keys"] >= 17 and a["env_steps_per_s"] > 0
     assert b["shapes"]["adj"] == (9, 48, 4, 8, 8) and b["edges_last_slot"] >= 0 and b["env_steps_per_s"] > 0
