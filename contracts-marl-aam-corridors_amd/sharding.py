@@ -232,8 +232,9 @@ class ShardedRolloutCollector(object):
         lst = list(self.gathered[b].unbind(0)) if self.rank == self.dst else None
         return d.gather(self.slabs[b], lst, dst=dst_global, group=g, async_op=True)
 
-    def collect_and_gather_async(self, action_sets, num_steps=None):
-        """One T-step rollout into the next slab (ONE launch), then start its gather; returns the slab index. The previous gather of that slab is waited for first."""
+    def collect_and_gather_async(self, action_sets):
+        """One WHOLE T-step rollout into the next slab (ONE launch; step k reads action_sets[k % S]), then start its gather; returns the slab index. The previous gather
+        of that slab is waited for first. (Partial rollouts have no place here: the slab that travels is a complete [T+1, N, ...] rollout.)"""
         b = self._flip
         self._flip ^= 1
         if self._work[b] is not None:
@@ -242,7 +243,7 @@ class ShardedRolloutCollector(object):
             self.bufs[b].carry_from(self.bufs[self._last])          # after_update across the two slabs: slot 0 <- the previous rollout's last slot
         elif self._last == b:
             self.bufs[b].after_update()
-        self.bufs[b].collect(action_sets, num_steps)
+        self.bufs[b].collect(action_sets)
         self._last = b
         self._work[b] = self._issue(b)
         return b
