@@ -560,8 +560,10 @@ def main():
         sc = {"navigation_graph": 1 if cfg.num_walls > 0 else 0, "nav_metered_one_goal_graph_rotate_tube_july": 2,
               "nav_graph_metered_single_corridor_rot_inv": 3, "two_phase_graph": 4, "three_phase_graph": 5}[wl["scenario_name"]]
         ap_roll = tuning["ap"] if (tuning["block_roll"] == 256 and tuning["ap"] == 10) else 0       # gmpe_sc.hip launch_env: what fl == 2 dispatches
-        k_step = "gmpe::k_env<%d, %d, %d, %d>" % (tuning["block"], tuning["ap"], sc, 1 if (tuning["block"] == 256 and tuning["ap"] == 10 and not tuning["nt"] and tuning["spec"]) else 0)
-        kernel = {"rollout": "gmpe::k_env<%d, %d, %d, 2> (persistent rollout: K steps per launch, G = %d envs per tile)" % (tuning["block_roll"], ap_roll, sc, tuning["G_roll"]),
+        gc_roll = tuning["G_roll"] if (ap_roll == 10 and tuning["G_roll"] in (4, 6)) else 0       # compile-time envs per tile (round 4)
+        fl_step = 1 if (tuning["block"] == 256 and tuning["ap"] == 10 and not tuning["nt"] and tuning["spec"]) else 0
+        k_step = "gmpe::k_env<%d, %d, %d, %d, %d>" % (tuning["block"], tuning["ap"], sc, fl_step, 4 if (fl_step and tuning["G"] == 4) else 0)
+        kernel = {"rollout": "gmpe::k_env<%d, %d, %d, 2, %d> (persistent rollout: K steps per launch, G = %d envs per tile)" % (tuning["block_roll"], ap_roll, sc, gc_roll, tuning["G_roll"]),
                   "launch-loop": k_step + " (one launch per step)" + (" + gmpe::k_adj_expand" if tuning["split"] and not args.adj_compact else ""),
                   "host-loop": k_step + " (one launch per step, Python loop)"}[mode]
         restated = wl["scenario_name"] == "navigation_graph"

@@ -809,8 +809,13 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
 // the single largest consumer of registers (187 -> 135 VGPRs), i.e. 2 -> 3 waves per SIMD for wall-less worlds.
 // FL = 1: the steady-state instantiation — step mode, wave specialisation on, ordinary stores, no ablation — with those run-time
 // flags folded (selected by the host when they hold; everything else takes FL = 0).
-template <int BLOCK, int AP, int SC, int FL>
-__global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL == 2 && BLOCK > 64 ? ((sc_rotfam(SC) || (AP > 0 && sc_kinematic(SC))) ? 3 : 4) : (AP > 0 && BLOCK > 64 ? (sc_rotfam(SC) ? 3 : 4) : GMPE_MIN_WAVES_NOWALLS)))) void k_env(const KParams p_arg) {
+// Register budgets of the step kernels (launch bounds below): four waves per SIMD for the exact-size ones except the rot_inv family, which needs ~131-137 VGPRs with run-time G (three waves); with
+// GC = 4 rot_inv and three_phase fit 128 (one dword / nothing spilled) and run four tiles per CU — closed loop 24.5 -> 23.1 and 25.1 -> 23.3 us per step — while two_phase would spill ten dwords (25.1 -> 28.3) and stays at three.
+// GC > 0: envs per tile known at compile time too (round 4; the exact-size rollout / steady-state instantiations at the tile shapes gmpe_create picks for 4096 x 10:
+// G = 4 and 6). Every LDS array base of the carve and every `g * E` then folds into an instruction offset instead of living in one of ~34 SGPRs or being recomputed
+// per use: navigation_graph's rollout kernel 128 -> 110 VGPRs with no scratch left, SGPR spills 130 -> 86, 5 % fewer instructions (profiles/r04_notes.md).
+template <int BLOCK, int AP, int SC, int FL, int GC = 0>
+__global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL == 2 && BLOCK > 64 ? ((sc_rotfam(SC) || (AP > 0 && sc_kinematic(SC))) ? 3 : 4) : (AP > 0 && BLOCK > 64 ? ((sc_rotfam(SC) && !(GC > 0 && SC != SC_TWO)) ? 3 : 4) : GMPE_MIN_WAVES_NOWALLS)))) void k_env(const KParams p_arg) {
     const KParams& p = p_arg;
     constexpr bool WALLS = SC == SC_NAV_WALLS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -827,7 +832,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
     // family needs ~130-150 VGPRs for that and is compiled for 3 waves per SIMD (the tile-shape search then packs 6 envs per tile);
     // the walls variant would lose a wave and keeps run-time sizes.
     constexpr bool CT = AP > 0 && SC != SC_NAV_WALLS;     // host: AP > 0 only if A == L == AP and O == 0
-    const int A = CT ? AP : p.A, L = CT ? AP : p.L, O = CT ? 0 : p.O, E = CT ? 2 * AP : p.E, D = CT ? (SC == SC_JULY ? 19 : (sc_phasefam(SC) ? 15 : 13)) : p.D, G = p.G, N = p.c.num_envs;
+    const int A = CT ? AP : p.A, L = CT ? AP : p.L, O = CT ? 0 : p.O, E = CT ? 2 * AP : p.E, D = CT ? (SC == SC_JULY ? 19 : (sc_phasefam(SC) ? 15 : 13)) : p.D, G = GC > 0 ? GC : p.G, N = p.c.num_envs;
     const gmpe_config& c = p.c;
     const Lds l = carve(smem, G, A, E, D, SC == SC_NAV_WALLS ? p.c.num_walls : 0, p.nfuse);
     const int n0 = p.env_lo + blockIdx.x * G;
@@ -1557,6 +1562,6 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
 // Host entry points of one scenario variant; defined and explicitly instantiated in gmpe_sc.hip (-DGMPE_SC=k).
 template <int SC> void launch_env(int block, int ap, int fl, dim3 grid, size_t lds, hipStream_t st, const KParams& p);
 template <int SC> hipError_t set_max_lds(int lds);
-template <int SC> int max_tiles_per_cu(int block, int ap, size_t lds, int roll);   // of the steady-state (FL = 1) instantiation where one exists; roll: of the rollout (FL = 2) one
+template <int SC> int max_tiles_per_cu(int block, int ap, size_t lds, int roll, int g = 0);   // of the steady-state (FL = 1) instantiation where one exists; roll: of the rollout (FL = 2) one; g: envs per tile (selects the compile-time-G instantiation where one exists)
 
 }  // namespace gmpe

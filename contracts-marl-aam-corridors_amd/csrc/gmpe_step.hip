@@ -290,14 +290,14 @@ static int sc_of(const gmpe_config& c) {
         default: return c.num_walls > 0 ? SC_NAV_WALLS : SC_NAV;
     }
 }
-static int sc_dispatch_occ(int sc, int block, int ap, size_t lds, int roll = 0) {
+static int sc_dispatch_occ(int sc, int block, int ap, size_t lds, int roll = 0, int g = 0) {
     switch (sc) {
-        case SC_NAV: return max_tiles_per_cu<SC_NAV>(block, ap, lds, roll);
-        case SC_NAV_WALLS: return max_tiles_per_cu<SC_NAV_WALLS>(block, ap, lds, roll);
-        case SC_JULY: return max_tiles_per_cu<SC_JULY>(block, ap, lds, roll);
-        case SC_ROT: return max_tiles_per_cu<SC_ROT>(block, ap, lds, roll);
-        case SC_TWO: return max_tiles_per_cu<SC_TWO>(block, ap, lds, roll);
-        default: return max_tiles_per_cu<SC_THREE>(block, ap, lds, roll);
+        case SC_NAV: return max_tiles_per_cu<SC_NAV>(block, ap, lds, roll, g);
+        case SC_NAV_WALLS: return max_tiles_per_cu<SC_NAV_WALLS>(block, ap, lds, roll, g);
+        case SC_JULY: return max_tiles_per_cu<SC_JULY>(block, ap, lds, roll, g);
+        case SC_ROT: return max_tiles_per_cu<SC_ROT>(block, ap, lds, roll, g);
+        case SC_TWO: return max_tiles_per_cu<SC_TWO>(block, ap, lds, roll, g);
+        default: return max_tiles_per_cu<SC_THREE>(block, ap, lds, roll, g);
     }
 }
 static hipError_t sc_dispatch_lds(int sc, int lds) {
@@ -582,7 +582,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
         for (int bi = 0; bi < 3 && !G; ++bi)
             for (int g = G0; g <= Gmax; ++g) {
                 const size_t tiles = (N + g - 1) / g;
-                const int per_cu = sc_dispatch_occ(sc_of(h->c), blocks[bi], ap_sel, lds_bytes(g, h->A, E, h->D, cfg->num_walls, 0));
+                const int per_cu = sc_dispatch_occ(sc_of(h->c), blocks[bi], ap_sel, lds_bytes(g, h->A, E, h->D, cfg->num_walls, 0), 0, g);
                 if (per_cu > 0 && tiles <= (size_t)per_cu * dev_cus) { G = g; block_sel = blocks[bi]; break; }
             }
     }
@@ -609,7 +609,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
             if (G0 < 1) G0 = 1;
             for (int g = G0; g <= Gmax && !Gr; ++g) {
                 const size_t tiles = (N + g - 1) / g;
-                const int per_cu = sc_dispatch_occ(sc_of(h->c), h->block_roll, ap_sel, lds_bytes(g, h->A, E, h->D, cfg->num_walls, nfuse_of(h, h->block_roll, ap_sel, 2)), 1);
+                const int per_cu = sc_dispatch_occ(sc_of(h->c), h->block_roll, ap_sel, lds_bytes(g, h->A, E, h->D, cfg->num_walls, nfuse_of(h, h->block_roll, ap_sel, 2)), 1, g);
                 if (per_cu > 0 && tiles <= (size_t)per_cu * dev_cus) Gr = g;
             }
         }
@@ -633,7 +633,7 @@ int gmpe_create(const gmpe_config* cfg, int device, gmpe_handle** out) {
         // adjacency is >= ~95 % of the bytes (A >= 48): c5 shapes (64 agents) 2048 envs 1515 us split vs 1731 fused, 4096: 2994 vs 3455,
         // 8192: 6043 vs 6565, 16384: 11618 vs 12981 (with the run-ahead bound below); c4 (A = 32) 1260 vs 1132: stays fused
         // (profiles/r02_notes.md). Everything else runs the fused kernel.
-        const size_t tiles_resident = (size_t)dev_cus * (size_t)[&] { const int q = sc_dispatch_occ(sc_of(h->c), block_sel ? block_sel : 256, ap_sel, lds_bytes(G, h->A, E, h->D, cfg->num_walls, 0)); return q > 0 ? q : 1; }();
+        const size_t tiles_resident = (size_t)dev_cus * (size_t)[&] { const int q = sc_dispatch_occ(sc_of(h->c), block_sel ? block_sel : 256, ap_sel, lds_bytes(G, h->A, E, h->D, cfg->num_walls, 0), 0, G); return q > 0 ? q : 1; }();
         const size_t tiles_total = (N + G - 1) / G;
         h->split = getenv("GMPE_SPLIT") ? atoi(getenv("GMPE_SPLIT"))
                                         : (out_bytes > 192.0 * 1024 * 1024 && h->A >= 48 ? 1 : 0);

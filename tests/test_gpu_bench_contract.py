@@ -33,7 +33,7 @@ def test_default_line_has_every_contract_field():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     # the headline launch writes slot-per-step storage (2.5 GB per pass: past the Infinity Cache), and names the instantiation that ran
-    assert r["dram_certain"] is True and "26" in c["launch"] and r["kernel"].startswith("gmpe::k_env<256, 10, 0, 2>")
+    assert r["dram_certain"] is True and "26" in c["launch"] and r["kernel"].startswith("gmpe::k_env<256, 10, 0, 2, 4>")
     assert r["launches"] == 1 and r["env_steps_per_launch"] == 4096 * 20      # the K steps are ONE launch of the rollout kernel
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     # achieved = algorithmic bytes per launch / average launch duration (HIP events on the launch stream)

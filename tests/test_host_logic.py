@@ -535,12 +535,14 @@ def test_kernels_do_not_spill():
     txt = out.stdout + out.stderr
     names = re.findall(r"Function Name: (\S*k_env\S*)", txt)
     scratch = re.findall(r"Function Name: \S*k_env\S*.*?ScratchSize \[bytes/lane\]: (\d+)", txt, flags=re.S)
-    assert len(names) >= 78 and len(scratch) == len(names)      # 6 scenario variants x (3 tile shapes x 3 exact sizes + the steady-state one + 3 rollout ones)
+    assert len(names) >= 96 and len(scratch) == len(names)      # 6 scenario variants x (3 tile shapes x 3 exact sizes + the steady-state one + 3 rollout ones)
     # Zero everywhere except two exact-size instantiations that sit at their 128-VGPR cap with a few dwords in cold paths and were
     # measured FASTER on one box than their spill-free alternatives (profiles/README.md): the July step kernels (3 dwords; c3 closed
     # loop 26.27 us vs 26.95 run-time sizes / 27.05 at three waves per SIMD) and navigation_graph's rollout kernel (5 dwords; c2
     # 17.0 us per step vs 18.3 at three tiles per CU without a spill / 19.9 run-time sizes).
-    allowed = lambda n: 16 if re.search(r"ELi10ELi2ELi[01]E", n) else (24 if "Li256ELi10ELi0ELi2E" in n else 0)
+    # Round 4: the compile-time-G variants (k_env<..., GC>) of those two are spill-free; rot_inv's GC = 4 step kernel is compiled for four waves per SIMD and keeps one dword
+    # in scratch — measured 6 % faster than three waves without it (profiles/r04_ab_rot_family_four_waves_abk.log).
+    allowed = lambda n: 16 if re.search(r"ELi10ELi2ELi[01]E", n) else (24 if "Li256ELi10ELi0ELi2E" in n else (8 if "Li256ELi10ELi3ELi1ELi4E" in n else 0))
     bad = [(n, x) for n, x in zip(names, scratch) if int(x) > allowed(n)]
     assert not bad, bad
 

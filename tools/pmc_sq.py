@@ -1,5 +1,5 @@
 """Summarise gpurun_out/sq{A,B}_<wl>/ (tools/pmc_sq.sh): SQ counters of the dominant k_env launches -> per tile-step figures."""
-import csv, glob, json, os, sys
+import csv, glob, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csv.field_size_limit(1 << 30)
 sys.path.insert(0, ROOT)
@@ -10,7 +10,7 @@ out = {}
 for p in ("sqA", "sqB"):
     f = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "%s_%s/**/*counter_collection.csv" % (p, wl)), recursive=True))
     if not f: continue
-    rows = [r for r in csv.DictReader(open(f[-1])) if "k_env" in r["Kernel_Name"] and ", 2>" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f[-1])) if "k_env" in r["Kernel_Name"] and re.search(r", 2(, \d+)?>", r["Kernel_Name"])]
     # the K-step rollout launches of the timed region are the longest ones: group by dispatch, keep those with the max WAVE_CYCLES class
     by = {}
     for r in rows:

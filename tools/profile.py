@@ -4,6 +4,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,7 +41,7 @@ def main(wl, tag="r02", steps="300", dirtag=None):
     fam = [r for r in keep if "k_env" in r["Name"] or "k_adj_expand" in r["Name"]]        # the step's kernels
     dom = max(fam, key=lambda r: float(r["TotalDurationNs"]))
     kenv = max([r for r in fam if "k_env" in r["Name"]], key=lambda r: float(r["TotalDurationNs"]))
-    roll = ", 2>" in kenv["Name"]
+    roll = re.search(r", 2(, \d+)?>", kenv["Name"]) is not None          # k_env<BLOCK, AP, SC, 2[, GC]>: the rollout instantiations
     split = any("k_adj_expand" in r["Name"] for r in fam)
     names = set(short(r["Name"]) for r in fam if short(r["Name"]) == short(kenv["Name"]) or "k_adj_expand" in r["Name"])
     vals = {}
