@@ -9,7 +9,21 @@
 #error "compile with -DGMPE_SC=<scenario variant>"
 #endif
 
+#ifndef GMPE_PART
+#define GMPE_PART 0
+#endif
+
 namespace gmpe {
+
+// The two steady-state step kernels (FL = 1: one launch per step, the closed-loop shape) live in a translation unit of their own (-DGMPE_PART=1) that is compiled with the max-ILP
+// machine scheduler (-mllvm -amdgpu-sched-strategy=max-ilp): a step launch is one dependent chain per tile, and scheduling for ILP instead of occupancy shortens it (c2 closed loop
+// 24.1 -> 23.6 us per step, c3 24.5 -> 24.2) while the rollout kernels, which interleave chains of several tiles, are 0.5 % faster with the default strategy (profiles/r04_notes.md).
+#if GMPE_PART == 1
+template __global__ void k_env<256, 10, GMPE_SC, 1>(const KParams);
+template __global__ void k_env<256, 10, GMPE_SC, 1, 4>(const KParams);
+#else
+extern template __global__ void k_env<256, 10, GMPE_SC, 1>(const KParams);
+extern template __global__ void k_env<256, 10, GMPE_SC, 1, 4>(const KParams);
 
 template <int SC>
 void launch_env(int block, int ap, int fl, dim3 grid, size_t lds, hipStream_t st, const KParams& p) {
@@ -80,5 +94,6 @@ int max_tiles_per_cu(int block, int ap, size_t lds, int roll, int g) {
 template void launch_env<GMPE_SC>(int, int, int, dim3, size_t, hipStream_t, const KParams&);
 template int max_tiles_per_cu<GMPE_SC>(int, int, size_t, int, int);
 template hipError_t set_max_lds<GMPE_SC>(int);
+#endif  // GMPE_PART
 
 }  // namespace gmpe

@@ -176,9 +176,12 @@ class GmpeEngine(object):
                              None if masks is None else masks.data_ptr(), None if active_masks is None else active_masks.data_ptr(),
                              int(st.get("entity_table", 0)))
         keep = (a, slot0, masks, active_masks)                           # the tensors behind the raw pointers stay alive with the callable
-        fn, h, ap, rp, op, stream, check = self.lib.gmpe_rollout_steps, self.h, a.data_ptr(), C.byref(r), C.byref(o), self._stream, _lib.check
+        eng, fn, ap, rp, op, stream, check = self, self.lib.gmpe_rollout_steps, a.data_ptr(), C.byref(r), C.byref(o), self._stream, _lib.check
 
         def launch(_keep=keep, _r=r, _o=o):
+            h = eng.h                                                    # read at launch time: a closed engine must fail loudly, not hand the C side a freed handle
+            if not h:
+                raise _lib.GmpeError("prepared rollout launched after the engine was closed")
             check(fn(h, ap, rp, op, stream()), "gmpe_rollout_steps")
         return launch
 

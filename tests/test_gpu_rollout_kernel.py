@@ -360,3 +360,24 @@ def test_timed_launch_shape_c4_slots_vs_oracle():
     K = n_slots + 4
     eng, n_resets = _bench_shape_rollout(kw, 8192, 64, K, n_slots)
     assert n_resets >= 64
+
+
+def test_prepared_rollout_is_the_same_launch_and_refuses_a_closed_engine():
+    """engine.prepare_rollout: argument structs built once, a call is one C call — same bits as rollout(); launching after close() raises instead of passing a freed handle."""
+    import torch
+    from gmpe._lib import GmpeError
+    cfg = gmpe.make_config(scenario_name="navigation_graph", num_envs=33, num_agents=10, world_size=4.0, episode_length=6, seed=5)
+    e1, e2 = _engine(cfg), _engine(cfg)
+    e1.reset(); e2.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(2)
+    acts = torch.randint(0, cfg.n_actions, (4, 33, 10), generator=g, device="cuda", dtype=torch.int32)
+    launch = e2.prepare_rollout(acts, 9)
+    for rep in range(3):
+        o1 = e1.rollout(acts, 9); launch()
+        torch.cuda.synchronize()
+        for key in OUT_KEYS:
+            assert torch.equal(getattr(o1, key), getattr(e2.out, key)), (rep, key)
+    _compare_state(e1, e2, "prepared launch")
+    e2.close()
+    with pytest.raises(GmpeError, match="closed"):
+        launch()

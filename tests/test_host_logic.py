@@ -542,7 +542,9 @@ def test_kernels_do_not_spill():
     # 17.0 us per step vs 18.3 at three tiles per CU without a spill / 19.9 run-time sizes).
     # Round 4: the compile-time-G variants (k_env<..., GC>) of those two are spill-free; rot_inv's GC = 4 step kernel is compiled for four waves per SIMD and keeps one dword
     # in scratch — measured 6 % faster than three waves without it (profiles/r04_ab_rot_family_four_waves_abk.log).
-    allowed = lambda n: 16 if re.search(r"ELi10ELi2ELi[01]E", n) else (24 if "Li256ELi10ELi0ELi2E" in n else (8 if "Li256ELi10ELi3ELi1ELi4E" in n else 0))
+    # The steady-state step kernels (FL = 1) are scheduled for ILP (Makefile STEPFLAGS): July's run-time-G one then keeps six dwords in scratch, rot_inv's GC = 4 one three — both measured
+    # faster that way (closed loop -1.2 % / -0.9 %, profiles/r04_ab_max_ilp*_abk.log).
+    allowed = lambda n: (24 if "Li256ELi10ELi2ELi1ELi0E" in n else 16) if re.search(r"ELi10ELi2ELi[01]E", n) else (24 if "Li256ELi10ELi0ELi2E" in n else (12 if "Li256ELi10ELi3ELi1ELi4E" in n else 0))
     bad = [(n, x) for n, x in zip(names, scratch) if int(x) > allowed(n)]
     assert not bad, bad
 
