@@ -147,6 +147,12 @@ __device__ __forceinline__ void nt_store4(float4* dst, const float4& v) {
     asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dst), "v"(x) : "memory");
 }
 
+#ifdef GMPE_ROW7_NT
+// experiment build (profiles/r04_notes.md): the seven scalar stores of a 28-byte node row with the nontemporal hint
+__device__ __forceinline__ void nt_store1(float* dst, float v) {
+    asm volatile("global_store_dword %0, %1, off nt\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+}
+#endif
 template <int SC>
 __device__ __forceinline__ void vel_of(double a2, double a3, double& vx, double& vy) {
     if (sc_kinematic(SC)) { double sn, cs; sincos(a2, &sn, &cs); vx = a3 * cs; vy = a3 * sn; }      // core.py:281-286
@@ -728,6 +734,13 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
                 rot2(cs, sn, (double)rpx, (double)rpy, o2, o3);
                 if (kag) rot2(cs, sn, (double)(gxk - apx), (double)(gyk - apy), o4, o5); else { o4 = o2; o5 = o3; }
                 float* dst = base + ((size_t)(gg * A + ei) * E + k) * 7;
+#ifdef GMPE_ROW7_NT
+                if (nt) {
+                    nt_store1(dst, (float)o0); nt_store1(dst + 1, (float)o1); nt_store1(dst + 2, (float)o2); nt_store1(dst + 3, (float)o3);
+                    nt_store1(dst + 4, (float)o4); nt_store1(dst + 5, (float)o5); nt_store1(dst + 6, typ);
+                    continue;
+                }
+#endif
                 dst[0] = (float)o0; dst[1] = (float)o1; dst[2] = (float)o2; dst[3] = (float)o3;
                 dst[4] = (float)o4; dst[5] = (float)o5; dst[6] = typ;
             }
