@@ -147,12 +147,6 @@ __device__ __forceinline__ void nt_store4(float4* dst, const float4& v) {
     asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dst), "v"(x) : "memory");
 }
 
-#ifdef GMPE_ROW7_NT
-// experiment build (profiles/r04_notes.md): the seven scalar stores of a 28-byte node row with the nontemporal hint
-__device__ __forceinline__ void nt_store1(float* dst, float v) {
-    asm volatile("global_store_dword %0, %1, off nt\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
-}
-#endif
 template <int SC>
 __device__ __forceinline__ void vel_of(double a2, double a3, double& vx, double& vy) {
     if (sc_kinematic(SC)) { double sn, cs; sincos(a2, &sn, &cs); vx = a3 * cs; vy = a3 * sn; }      // core.py:281-286
@@ -707,7 +701,8 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
     if (sc_rotfam(SC) && o.node_obs && !(abl & 2) && p.c.graph_feat_type != 1) {
         // rot_inv node row (…rot_inv.py:1690-1766): 7 float32 = [rel_vel, rel_pos, rel_goal (all rotated by the ego heading), type].
         // Positions / velocities are rounded to float32 FIRST, differenced in float32, rotated in float64, rounded again.
-        // A lane owns one (env, entity) and walks the egos; rows are 28 B, so the stores are scalar.
+        // A lane owns one (env, entity) and walks the egos; rows are 28 B, so the stores are scalar — and ordinary: L2 merges the seven dwords of a row into whole lines,
+        // with the nontemporal hint they reach HBM as partial writes (26-slot rot_inv rollout 19.3 -> 76 us per step, profiles/r04_notes.md).
         float* base = o.node_obs + (size_t)n0 * A * E * 7;
         for (int sidx = t0; sidx < Gv * E; sidx += nthr) {
             const int gg = fdiv(sidx, E, p.m_E), k = sidx - gg * E;
@@ -734,13 +729,6 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
                 rot2(cs, sn, (double)rpx, (double)rpy, o2, o3);
                 if (kag) rot2(cs, sn, (double)(gxk - apx), (double)(gyk - apy), o4, o5); else { o4 = o2; o5 = o3; }
                 float* dst = base + ((size_t)(gg * A + ei) * E + k) * 7;
-#ifdef GMPE_ROW7_NT
-                if (nt) {
-                    nt_store1(dst, (float)o0); nt_store1(dst + 1, (float)o1); nt_store1(dst + 2, (float)o2); nt_store1(dst + 3, (float)o3);
-                    nt_store1(dst + 4, (float)o4); nt_store1(dst + 5, (float)o5); nt_store1(dst + 6, typ);
-                    continue;
-                }
-#endif
                 dst[0] = (float)o0; dst[1] = (float)o1; dst[2] = (float)o2; dst[3] = (float)o3;
                 dst[4] = (float)o4; dst[5] = (float)o5; dst[6] = typ;
             }
