@@ -295,6 +295,87 @@ __device__ __forceinline__ double win_draw(const KParams& p, double* buf, int64_
     return v;
 }
 
+// ---- batched placement (exact-size rollout kernels; reset_world_coop<SC, true>) ----
+// sqrt(dx^2 + dy^2) < thr — the rejection test of the placement loops (…_july.py:895-904) — decided on the squared distance unless it lies within a relative
+// 1e-12 of thr^2, where the exact comparison runs: with a correctly rounded sqrt (relative error 1.1e-16) the two outer cases cannot disagree with it.
+__device__ __forceinline__ bool closer_than(double dx, double dy, double thr) {
+    const double d2 = dx * dx + dy * dy, t2 = thr * thr;
+    if (d2 < t2 * (1.0 - 1e-12)) return true;
+    if (d2 > t2 * (1.0 + 1e-12)) return false;
+    return sqrt(d2) < thr;
+}
+// One draw of env n's stream: the tape value (0.5 past its end: draw_at's rule) or Philox. The sticky tape-exhausted bit is set by the caller from the final
+// counter — exactly the draws [ctr_in, ctr_out) of a reset are consumed, whatever was evaluated speculatively.
+__device__ __forceinline__ double draw_raw(const KParams& p, int n, int64_t k) {
+    if (p.s.tape) return k < p.s.tape_len ? p.s.tape[(size_t)n * p.s.tape_len + k] : 0.5;
+    return philox_uniform(p.c.seed, (uint32_t)(p.c.env_id_base + n), (uint64_t)k);
+}
+__device__ __forceinline__ void wave_lds_sync() {                           // LDS operations of one wave execute in order: the fences pin the compiler's order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Draws of a resetting env for the batched placement: the tile's streaming waves evaluate the first `nd` draws of the env's stream from its reset counter on
+// (k_env: while wave 0 computes the terminal step's rewards / info) into the env's fp32-matrix region, which is dead between the step's distance pass and the reset's;
+// a placement round then READS its draws instead of evaluating Philox inside its chain. Draws past the buffer (a reset that rejects unusually often) are evaluated in place.
+struct DrawBuf { const double* d; int64_t base; int nd; };
+__device__ __forceinline__ double buf_get(const KParams& p, const DrawBuf& w, int n, int64_t k) {
+    const int64_t o = k - w.base;
+    return o < w.nd ? w.d[o] : draw_raw(p, n, k);
+}
+// navigation_graph placement of one entity class (M entities at ex/ey[base ...], pairwise at least `thr` apart, optionally clear of obstacles / wall bands) by
+// greedy rejection in stream order — attempt t uses draws (ctr + 2t, ctr + 2t + 1) and is accepted iff it is clear of everything accepted before it, or it is the
+// GMPE_MAX_TRIES-th consecutive failure for its entity (oracle/gmpe_oracle.c restates the loop literally). The candidates do not depend on what was accepted, so
+// the A lanes of the env evaluate A consecutive attempts at once: lane i tests attempt i against the entities placed by earlier batches and against the earlier
+// attempts of its batch (a bit mask), and every lane replays the greedy decisions of the batch on those masks — a handful of bit operations per attempt instead
+// of a dependent LDS / fp64 chain per attempt.
+__device__ __forceinline__ void place_uniform(const KParams& p, const Lds& l, const DrawBuf& win, int n, int i, bool mine, unsigned long long emask, int M, int base, double thr,
+                                              bool check_static, bool is_agent, int64_t& ctr, int& err) {
+    const gmpe_config& c = p.c;
+    const int A = p.A, O = p.O, o0 = p.A + p.L;
+    const double ws = c.world_size, size = c.entity_size, lo = -ws / 2, hi = ws / 2;
+    const int lane0 = emask ? __ffsll((long long)emask) - 1 : 0;
+    double* cx = l.vox; double* cy = l.voy;                                 // batch scratch: rows of the env that the re-initialisation after the placement rewrites
+    unsigned long long* cm = reinterpret_cast<unsigned long long*>(l.vnx);
+    int k = 0, tries = 0;
+    while (__ballot(mine && k < M)) {
+        if (mine && k < M) {
+            const double px = 0.8 * (lo + (hi - lo) * buf_get(p, win, n, ctr + 2 * i));
+            const double py = 0.8 * (lo + (hi - lo) * buf_get(p, win, n, ctr + 2 * i + 1));
+            bool bad0 = false;
+            if (check_static) {
+                bad0 = wall_band_hit(p, px, py, size);
+                for (int o = 0; o < O; ++o) bad0 = bad0 || closer_than(l.ex[o0 + o] - px, l.ey[o0 + o] - py, 2.0 * (size + size));
+            }
+            for (int q = 0; q < k; ++q) bad0 = bad0 || closer_than(l.ex[base + q] - px, l.ey[base + q] - py, thr);
+            cx[i] = px; cy[i] = py;
+            wave_lds_sync();
+            unsigned long long cl = 0ull;
+            for (int j = 0; j < i; ++j) if (closer_than(cx[j] - px, cy[j] - py, thr)) cl |= 1ull << j;
+            cm[i] = cl;
+            wave_lds_sync();
+            const unsigned long long bad = (__ballot(bad0) & emask) >> lane0;   // bit j: attempt j fails against the entities of earlier batches / statics
+            unsigned long long acc = 0ull;
+            int kk = k, t = tries, used = 0, slot = -1;
+            for (int j = 0; j < A && kk < M; ++j) {                          // env-uniform: every lane of the env replays the same decisions
+                const bool b = ((bad >> j) & 1ull) || (cm[j] & acc) != 0ull;
+                used = j + 1;
+                if (b && ++t < GMPE_MAX_TRIES) continue;
+                if (b) err |= 2;
+                if (j == i) slot = kk;
+                acc |= 1ull << j; ++kk; t = 0;
+            }
+            wave_lds_sync();                                                 // everybody has read the batch before the next one overwrites it
+            if (slot >= 0) {
+                l.ex[base + slot] = px; l.ey[base + slot] = py;
+                if (is_agent) { l.n2[slot] = 0.0; l.n3[slot] = 0.0; }
+            }
+            wave_lds_sync();
+            ctr += 2 * used; k = kk; tries = t;
+        }
+    }
+}
+
 // Reset of the envs of a tile by wave 0 (reset_world: …_july.py:339-420, 440-515, 518-613, custom_scenarios/utils.py:165-193;
 // navigation_graph: DESIGN.md). The reference places entities one after another with rejection sampling — inherently sequential
 // in the entity index, but each attempt's collision test against the already placed entities is not: every agent lane of the env
@@ -307,14 +388,24 @@ __device__ __forceinline__ double win_draw(const KParams& p, double* buf, int64_
 // (ex, ey, n2, n3, tube) and landmark / obstacle / tube records to HBM.
 // (Round 4 tried computing the NEXT episode's placement ahead of the reset — exact, since a reset is a pure function of the env's draw counter — on wave 3 of a
 // steady rollout step: the second copy of this loop in the step loop cost more registers than the shorter reset step gave back; profiles/r04_placement_ahead_experiment.patch.)
-template <int SC>
+// BATCH (exact-size rollout kernels): the attempts themselves run in parallel. Kinematic scenarios — the candidate of agent k depends on k (its slot on the line) and
+// an accepted agent consumes one more draw (its heading), so the A lanes of the env evaluate A consecutive attempts of the CURRENT agent at once and the first clear
+// one (or the GMPE_MAX_TRIES-th failure) wins; navigation_graph — candidates are independent of what was accepted, so a batch of A attempts is resolved greedily in
+// stream order (place_uniform). Draws are read from the env's prefilled buffer (DrawBuf). Same placements, draw order and counters (the GPU tests compare placements and RNG counters with the
+// oracle's literal loops). Used by the exact-size ROLLOUT kernels of navigation_graph and July (k_env below): all-env reset step 32-44 -> 26-31 us at c2, 48-59 -> 40-45 at c3,
+// rollouts -1...-2 % (profiles/r04_ab_batched_placement_abk.log). Not by the step kernels (round 3: at their register cap they lost more than the reset gained) and not by the
+// rot_inv family, whose wider jitter rejects little — its rounds stay ~A and each batched round costs more (reset step 30-34 -> 41-43 us).
+template <int SC, bool BATCH = false>
 __device__ __forceinline__ void reset_world_coop(const KParams& p, const Lds& l, int n, int i, bool mine, unsigned long long emask, int64_t& ctr, int& err) {
     const gmpe_config& c = p.c;
     const double ws = c.world_size, size = c.entity_size;
     const int A = p.A, L = p.L, O = p.O;
     const int o0 = A + L;
     int64_t wbase = -(int64_t)A - 1;                                        // empty window; slots = the env's spacing-error row (consumed before a reset)
-#define WDRAW(k) win_draw(p, l.serr, wbase, A, n, i, (k), err)
+    const int64_t ctr_in = ctr;
+    const DrawBuf win = {reinterpret_cast<const double*>(l.M), ctr, BATCH ? (p.E * p.E + 3) / 4 * 2 : 0};   // BATCH: the env's prefilled draws (k_env)
+    const int lane0 = emask ? __ffsll((long long)emask) - 1 : 0;
+#define WDRAW(k) (BATCH ? buf_get(p, win, n, (k)) : win_draw(p, l.serr, wbase, A, n, i, (k), err))
     if (sc_kinematic(SC)) {
         double entx = 0, enty = 0, exx = 0, exy = 0, sa = 0, ca = 1;
         if (mine) {
@@ -341,7 +432,34 @@ __device__ __forceinline__ void reset_world_coop(const KParams& p, const Lds& l,
         }
         int k = 0, tries = 0;
         double mx = 0, my = 0;                                              // agent i's accepted position (this lane owns agent i)
-        while (__ballot(mine && k < A)) {
+        if constexpr (BATCH) while (__ballot(mine && k < A)) {
+            if (mine && k < A) {
+                // lane i evaluates attempt i of agent k: draws (ctr + 2i, ctr + 2i + 1); the accepted attempt's heading draw follows them
+                const double u0 = buf_get(p, win, n, ctr + 2 * i), u1 = buf_get(p, win, n, ctr + 2 * i + 1);
+                constexpr bool rot = sc_rotfam(SC);             // rot_inv.py:463, 469
+                const double jf = rot ? 0.3 : 0.2;
+                const double jx = jf * (-ws + (ws - (-ws)) * u0), jy = jf * (-ws + (ws - (-ws)) * u1);
+                const double dfe = rot ? (ws + k) / 3 : (ws + k) / 5;
+                const double px = entx + dfe * sa + jx, py = enty + dfe * ca + jy;
+                bool bad_i = wall_band_hit(p, px, py, size);
+                for (int o = 0; o < O; ++o) bad_i = bad_i || closer_than(l.ex[o0 + o] - px, l.ey[o0 + o] - py, 2.0 * (size + size));
+                for (int q = 0; q < k; ++q) bad_i = bad_i || closer_than(l.ex[q] - px, l.ey[q] - py, c.sep_dist);
+                const unsigned long long all = emask >> lane0;
+                const unsigned long long good = ~((__ballot(bad_i) & emask) >> lane0) & all;
+                const int jg = good ? __ffsll((long long)good) - 1 : A;      // first clear attempt of the batch
+                const int jfo = GMPE_MAX_TRIES - 1 - tries;                  // the attempt that is accepted even if it fails (the reference would spin forever)
+                int js;
+                if (jfo < A && jfo < jg) { js = jfo; err |= 2; }
+                else if (jg < A) js = jg;
+                else { tries += A; ctr += 2 * A; continue; }
+                ctr += 2 * (js + 1);
+                const double th = 0.0 + (2 * M_PI - 0.0) * buf_get(p, win, n, ctr); ++ctr;
+                if (i == js) { l.ex[k] = px; l.ey[k] = py; l.n2[k] = th; l.n3[k] = c.v_min; }
+                wave_lds_sync();
+                ++k; tries = 0;
+            }
+        }
+        else while (__ballot(mine && k < A)) {
             if (mine && k < A) {
                 const double u0 = WDRAW(ctr), u1 = WDRAW(ctr + 1);
                 ctr += 2;
@@ -390,6 +508,14 @@ __device__ __forceinline__ void reset_world_coop(const KParams& p, const Lds& l,
                 const double rx = ca * 0.0 + sa * rel, ry = -sa * 0.0 + ca * rel;
                 for (int q = i; q < L; q += A) { l.ex[A + q] = exx + rx; l.ey[A + q] = exy + ry; }
             }
+        }
+    } else if constexpr (BATCH) {
+        place_uniform(p, l, win, n, i, mine, emask, O, o0, 2.0 * (size + size), false, false, ctr, err);   // obstacles: >= 2*(size+size) apart
+        place_uniform(p, l, win, n, i, mine, emask, A, 0, c.sep_dist, true, true, ctr, err);               // agents: clear of obstacles / wall bands, >= sep_dist apart
+        place_uniform(p, l, win, n, i, mine, emask, L, A, c.sep_dist, true, false, ctr, err);              // goals (landmarks): likewise
+        if (mine) for (int o = i; o < O; o += A) {
+            p.s.obstacles[((size_t)n * O + o) * 2] = l.ex[o0 + o];
+            p.s.obstacles[((size_t)n * O + o) * 2 + 1] = l.ey[o0 + o];
         }
     } else {
         const double lo = -ws / 2, hi = ws / 2;
@@ -453,6 +579,7 @@ __device__ __forceinline__ void reset_world_coop(const KParams& p, const Lds& l,
         p.s.landmarks[((size_t)n * L + q) * 2] = l.ex[A + q];
         p.s.landmarks[((size_t)n * L + q) * 2 + 1] = l.ey[A + q];
     }
+    if (BATCH && mine && p.s.tape && ctr > ctr_in && ctr > p.s.tape_len) err |= 1;    // a consumed draw lay past the tape (draw_at's sticky bit)
 }
 #undef WDRAW
 
@@ -795,6 +922,9 @@ __device__ __forceinline__ void stream_graph_fn(const KParams& p, const gmpe_out
     }
 }
 
+#ifndef GMPE_BATCHED_PLACEMENT
+#define GMPE_BATCHED_PLACEMENT 1    /* exact-size navigation_graph / July rollout kernels place a resetting env's entities in batches of A attempts (reset_world_coop<SC, true>) */
+#endif
 #ifndef GMPE_MIN_WAVES
 #define GMPE_MIN_WAVES 1
 #endif
@@ -842,6 +972,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
     constexpr int PV = two ? 1 : (three ? 2 : 0);                        // phase FSM variant (gmpe_device.h)
     const bool step = FL ? true : p.mode == MODE_STEP;
     constexpr bool kin = sc_kinematic(SC);
+    constexpr bool BATCHK = FL == 2 && AP > 0 && BLOCK > 64 && !sc_rotfam(SC) && SC != SC_NAV_WALLS && GMPE_BATCHED_PLACEMENT;   // batched placement from prefilled draws (reset_world_coop<SC, true>)
     const int EE = E * E, EE4 = (EE + 3) / 4 * 4, AD4 = (A * D + 3) / 4 * 4;
     const double INF = __builtin_huge_val();
 
@@ -1160,6 +1291,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
                 const unsigned long long mbal = __ballot(ag && (v.moff[i] | v.moff[A + i]));
                 all_done = ag && ((dbal & emask) == emask);
                 if (ag && i == 0) { v.flags[0] = all_done; v.flags[2] = (mbal & emask) != 0ull; }
+                if (BATCHK && all_done && i == 0) reinterpret_cast<long long*>(l.cntd + (size_t)G * A * 2 + G)[g] = ctr0 + ndraw;   // where the reset's draws start (read by the streaming waves below)
             }
             __syncthreads();
             STAMP(5);
@@ -1178,6 +1310,17 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
         // graph observations, so the ~7 us of per-agent arithmetic runs beside the store issue instead of after it.
         const bool spec = early && BLOCK > 64 && (FL ? true : p.spec != 0);
         if (early && !spec) stream_graph_fn<BLOCK, AP, SC, FL>(p, out, l, Gv, n0, tid, tid, BLOCK, true, any_mask);
+        if constexpr (BATCHK) if (any_reset && tid >= 64) {
+            // batched placement (reset_world_coop<SC, true>): the streaming waves, idle in a step with a reset, evaluate the resetting envs' draws while wave 0 computes the
+            // terminal rewards / info; the barrier in front of section 5 publishes them
+            const int ND = EE4 / 2;
+            for (int q = tid - 64; q < Gv * ND; q += BLOCK - 64) {
+                const int gg = q / ND, d = q - gg * ND;
+                if (!l.flags[gg * 4 + 0]) continue;
+                const int64_t c0 = reinterpret_cast<const long long*>(l.cntd + (size_t)G * A * 2 + G)[gg];
+                reinterpret_cast<double*>(l.M + (size_t)gg * EE4)[d] = draw_raw(p, n0 + gg, c0 + d);
+            }
+        }
         if (spec) {
             if (any_mask && !(abl & 4)) {
                 for (int q = tid; q < Gv * EE; q += BLOCK) {
@@ -1460,7 +1603,7 @@ __global__ __launch_bounds__(BLOCK, (SC == SC_NAV_WALLS ? GMPE_MIN_WAVES : (FL =
                 if (tid < 64) {                                                   // wave 0 holds every agent lane: placement is a wave-cooperative loop
                     int64_t ctr = ctr0 + ((mine && step) ? v.flags[1] : 0);      // this step's heading re-draws come first
                     STAMP(20);
-                    reset_world_coop<SC>(p, v, n, i, mine, emask, ctr, err);
+                    reset_world_coop<SC, BATCHK>(p, v, n, i, mine, emask, ctr, err);
                     STAMP(21);
                     if (mine && i == 0) {
                         if (ROLL) reinterpret_cast<long long*>(l.cntd + (size_t)G * A * 2 + G)[g] = ctr;
