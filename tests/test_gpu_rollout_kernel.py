@@ -381,3 +381,46 @@ def test_prepared_rollout_is_the_same_launch_and_refuses_a_closed_engine():
     e2.close()
     with pytest.raises(GmpeError, match="closed"):
         launch()
+
+
+@pytest.mark.parametrize("scen,ws,tape_len,expect", [("navigation_graph", 2.5, 0, "clean"), (JULY, 3.0, 0, "clean"), ("navigation_graph", 2.0, 0, "forced"), (JULY, 2.5, 0, "forced"),
+                                                     ("navigation_graph", 4.0, 170, "tape"), (JULY, 4.0, 150, "tape")],
+                         ids=["nav-ws2.5", "july-ws3", "nav-ws2-forced", "july-ws2.5-forced", "nav-tape-runs-out", "july-tape-runs-out"])
+def test_batched_placement_crowded_worlds_and_short_tapes_vs_oracle(scen, ws, tape_len, expect):
+    """The exact-size rollout kernels of navigation_graph / July place a resetting env's entities in batches of A attempts from draws the streaming waves
+    prefilled (reset_world_coop<SC, true>). Crowded worlds make a reset consume MORE draws than the 200-draw buffer holds (evaluated in place) and hit the
+    GMPE_MAX_TRIES forced accepts (error bit 2, which the oracle's literal loop sets for the same envs); a short RNG tape runs out inside the rollout (error bit 1,
+    draws past its end read 0.5). Placements, RNG counters, error flags and every output must equal the oracle's sequential loops (…_july.py:440-515)."""
+    import torch
+    N, A, K = 44, 10, 11
+    if expect == "tape" and scen == "navigation_graph":
+        K = 8        # the tape runs out in the LAST step's auto-reset: past its end every draw is 0.5, the agents coincide and the next step's contact forces are 0 / 0 in engine and oracle alike
+    cfg = gmpe.make_config(scenario_name=scen, num_envs=N, num_agents=A, world_size=ws, episode_length=4, seed=311)
+    eng, orc = _engine(cfg), ol.Oracle(cfg)
+    assert eng.tuning()["ap"] == 10 and eng.tuning()["block_roll"] == 256           # the instantiation with the batched placement
+    if tape_len:
+        tape = np.random.RandomState(12).rand(N, tape_len)
+        eng.set_tape(tape); orc.set_tape(tape)
+    eng.reset(); orc.reset()
+    rng = np.random.RandomState(6)
+    acts = rng.randint(0, cfg.n_actions, (K, N, A)).astype(np.int32)
+    st = _rollout_into_slots(eng, torch.as_tensor(acts, device="cuda"), K, K)
+    biggest_reset, prev = 0, orc.get("rng_ctr").copy()
+    for k in range(K):
+        oo = orc.step(acts[k])
+        now = orc.get("rng_ctr")
+        biggest_reset, prev = max(biggest_reset, int((now - prev).max())), now.copy()   # draws of one step: <= A heading re-draws + an auto-reset's placement
+        np.testing.assert_allclose(_np(st["obs"][k]), oo[0], rtol=0, atol=TOL, err_msg="obs %d" % k)
+        np.testing.assert_allclose(_np(st["node_obs"][k]), oo[2], rtol=0, atol=TOL, err_msg="node %d" % k)
+        np.testing.assert_allclose(_np(st["adj"][k]), np.broadcast_to(oo[3][:, None], st["adj"][k].shape), rtol=0, atol=TOL, err_msg="adj %d" % k)
+        np.testing.assert_allclose(_np(st["reward"][k]), oo[4], rtol=0, atol=TOL, err_msg="rew %d" % k)
+        np.testing.assert_array_equal(_np(st["done"][k]).astype(bool), oo[5], err_msg="done %d" % k)
+    _compare_state(eng, orc, "end")                                                  # positions, landmarks, rng_ctr and error_flags included
+    ctr, err = orc.get("rng_ctr"), orc.get("error_flags")
+    assert biggest_reset > 200 + A                                                   # an auto-reset inside the rollout drew past the prefilled buffer
+    if expect == "tape":
+        assert (err & 1).any() and (ctr > tape_len).any()                            # the tape did run out inside the rollout
+    elif expect == "forced":
+        assert (err & 2).any()                                                       # forced accepts happened
+    else:
+        assert not err.any()
