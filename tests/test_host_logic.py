@@ -581,3 +581,13 @@ def test_bench_cpu_baseline_runs_at_host_scale():
     assert cb["value"] > 0 and cb["single_thread"] > 0 and abs(cb["per_core"] * cb["cores"] - cb["value"]) < 1e-6 * cb["value"]
     if usable >= 4:
         assert cb["value"] > 1.5 * cb["single_thread"]          # the C call releases the GIL: threads really run in parallel
+
+
+def test_plain_c_consumer_of_the_abi_compiles_and_links(tmp_path):
+    """examples/c_abi_consumer.c — a consumer that is neither Python nor torch — builds with gcc -std=c11 -Wall -Werror against include/gmpe.h and links against
+    libgmpe.so + the HIP runtime (it RUNS in tests/test_gpu_c_consumer.py)."""
+    from c_consumer_build import build_c_consumer
+    exe = build_c_consumer(str(tmp_path))
+    assert os.path.exists(exe)
+    needed = subprocess.check_output(["ldd", exe]).decode()
+    assert "libgmpe.so" in needed and "libamdhip64" in needed and "torch" not in needed
