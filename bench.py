@@ -284,7 +284,10 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     dist = None
-    if world > 1:
+    # GMPE_BENCH_NCCL_SOLO=1 (tests): take the multi-rank branch with a ONE-rank RCCL group, so that the backend-"nccl" code path the driver's N > 1 runs use —
+    # process group bound to the device, barriers, the on-device MAX reduction, the gathers — executes on a one-GPU box too (RCCL refuses two ranks on one device)
+    solo = world == 1 and os.environ.get("GMPE_BENCH_NCCL_SOLO") == "1" and "MASTER_ADDR" in os.environ
+    if world > 1 or solo:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # backend "nccl" IS RCCL on ROCm. GMPE_BENCH_REHEARSAL=1: gloo + every rank on device 0, to rehearse the

@@ -108,3 +108,22 @@ def test_two_rank_rehearsal_of_the_multi_gpu_bench_path():
     assert ro["value"] > 0 and ro["steps_per_rollout"] == 25 and ro["bytes_per_env_step"] < 0.2 * ro["bytes_per_env_step_rows_form"]
     assert abs(ro["slab_bytes_per_rank"] / (25 * 512) - ro["bytes_per_env_step"]) < 64
     assert "cpu_baseline" not in d and "one_slot" not in d     # N = 1 only
+
+
+def test_one_rank_rccl_run_of_the_multi_gpu_bench_branch():
+    """The rehearsal above swaps RCCL for gloo (two ranks cannot share a device under RCCL). This one keeps backend "nccl" = RCCL and runs the same multi-rank branch
+    with ONE rank under torch.distributed.run (GMPE_BENCH_NCCL_SOLO=1): process group bound to the device before any GPU work, barriers, the on-device MAX reduction
+    of the timing, both gathers over RCCL and the learner-side expansion — what the driver's N > 1 commands execute, minus the peers."""
+    env = dict(os.environ, GMPE_BENCH_NCCL_SOLO="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29900 + os.getpid() % 90
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--reps", "2", "--gather", "--no-cpu-baseline", "--no-boundary"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["config"]["envs_per_gpu"] == 4096
+    assert d["verified"]["ints_exact"] is True and d["verified"]["max_abs_err"] < 1e-5
+    assert d["with_gather"]["value"] > 0 and d["with_gather"]["rollout"]["value"] > 0            # both gathers ran over RCCL
+    assert d["roofline"]["frac"] > 0.3
