@@ -9,7 +9,7 @@
 typedef float v4f __attribute__((ext_vector_type(4)));
 template <bool NT>
 __global__ __launch_bounds__(256) void tile_store(v4f* __restrict__ adj, v4f* __restrict__ node, v4f* __restrict__ obs, int K, int T, size_t adj_slot4, size_t node_slot4,
-                                                  size_t obs_slot4, int adj4, int node4, int obs4, int streamers, long long gap) {
+                                                  size_t obs_slot4, int adj4, int node4, int obs4, int streamers, long long gap, int nosync = 0) {
     const int tid = threadIdx.x, w = tid >> 6;
     const v4f val = {1.f, 2.f, 3.f, (float)tid};
     const int first = 256 - streamers * 64;                            // the LAST `streamers` waves store
@@ -27,12 +27,13 @@ __global__ __launch_bounds__(256) void tile_store(v4f* __restrict__ adj, v4f* __
             const long long t0 = __builtin_readcyclecounter();
             while ((long long)__builtin_readcyclecounter() - t0 < gap) __builtin_amdgcn_s_sleep(8);
         }
-        __syncthreads();
+        if (!nosync) __syncthreads();                                     // nosync: every wave free-runs through the K steps (what a tile whose streaming waves are decoupled from its step barrier could reach)
     }
 }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 // With arguments — tilebw.bin <label> <tiles> <adj float4 per tile> <node float4 per tile> <obs float4 per tile> <T slots> <K steps> — it measures ONE geometry (streamers 3 / 4,
 // plain / nontemporal, no gap) and prints a JSON line with the best rate: the store ceiling bench.py prices `frac_of_measured_fill` against (tools/fillbw_r04.sh -> profiles/r04_fillbw.json).
+static int g_nosync = 0;
 static int one_geometry(const char* label, int tiles, int adj4, int node4, int obs4, int T, int K) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double step_bytes = (double)tiles * (adj4 + node4 + obs4) * 16;
@@ -41,8 +42,8 @@ static int one_geometry(const char* label, int tiles, int adj4, int node4, int o
     double best = 0; int best_s = 0, best_nt = 0;
     for (int streamers : {3, 4}) for (int nt = 0; nt < 2; ++nt) {
         auto launch = [&] {
-            if (nt) tile_store<true><<<tiles, 256>>>(adj, node, obs, K, T, (size_t)tiles * adj4, (size_t)tiles * node4, (size_t)tiles * obs4, adj4, node4, obs4, streamers, 0);
-            else tile_store<false><<<tiles, 256>>>(adj, node, obs, K, T, (size_t)tiles * adj4, (size_t)tiles * node4, (size_t)tiles * obs4, adj4, node4, obs4, streamers, 0);
+            if (nt) tile_store<true><<<tiles, 256>>>(adj, node, obs, K, T, (size_t)tiles * adj4, (size_t)tiles * node4, (size_t)tiles * obs4, adj4, node4, obs4, streamers, 0, g_nosync);
+            else tile_store<false><<<tiles, 256>>>(adj, node, obs, K, T, (size_t)tiles * adj4, (size_t)tiles * node4, (size_t)tiles * obs4, adj4, node4, obs4, streamers, 0, g_nosync);
         };
         launch(); CK(hipDeviceSynchronize());
         double ms_best = 1e30;
@@ -61,6 +62,7 @@ static int one_geometry(const char* label, int tiles, int adj4, int node4, int o
     return 0;
 }
 int main(int argc, char** argv) {
+    if (argc == 9) { g_nosync = atoi(argv[8]); argc = 8; }                   // optional 8th argument: 1 = no per-step workgroup barrier
     if (argc == 8) return one_geometry(argv[1], atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]));
 
     const int tiles = 1024, adj4 = 4 * 10 * 400 / 4, node4 = 4 * 10 * 20 * 8 / 4, obs4 = 4 * 10 * 13 / 4 + 2;   // c2: 4 envs per tile
